@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — pose-net triplets/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the hot path (SE squeeze + excite, mask/pack, 8 conv layers, pose head)
+over one batch of synthetic triplets that is already resident in HBM.  At N=1 the workload is
+BASELINE.json configs[1]: batch 32, 128x416, flagship variant
+(dilatedPoseNN-cnv6_128 + se_flow + fc_tanh).  For N>1 every rank runs the same per-GPU batch on
+its own windows (weak scaling, no data-path collective: windows are independent,
+test_kitti_pose.py:134-145); after the timed region the ranks' poses are gathered once over
+RCCL, which is reported separately and is not part of `value`.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--height H --width W]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# FLOPs of one PoseNN pair evaluation at 128x416, SURVEY.md §8a table L (MACs x 2)
+MACS_PER_PAIR_128x416 = 3890085888
+CNV6_MACS_PER_PAIR_128x416 = 2 * 981467136          # rotation + translation cnv6, fused into one launch
+PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: FP32 matrix, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="triplets per GPU per step")
+    ap.add_argument("--height", type=int, default=128)
+    ap.add_argument("--width", type=int, default=416)
+    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic windows generated per rank (tiled to the batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="triplets per CPU-baseline pass")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch                                     # plumbing only: barrier / synchronize / RCCL gather
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from davo_amd import Engine, synth, parse_version, FLAGSHIP_VERSION
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B, H, W = args.batch, args.height, args.width
+    scale_px = (H * W) / float(128 * 416)
+    flops_per_triplet = 2 * 2 * MACS_PER_PAIR_128x416 * scale_px
+    cnv6_flops_per_launch = 2 * CNV6_MACS_PER_PAIR_128x416 * scale_px * (2 * B)
+
+    weights = synth.make_weights(cfg)
+    eng = Engine(cfg, H, W, B, device=local_rank)
+    eng.load_weights(weights)
+
+    # synthetic windows of this rank's shard, resident in HBM before the timed region
+    nu = max(1, min(args.unique, B))
+    img_u, flow_u, seg_u = synth.make_inputs(nu, H, W, first_window=rank * B)
+    reps = -(-B // nu)
+    img = np.tile(img_u, (reps, 1, 1, 1))[:B]
+    flow = np.tile(flow_u, (reps, 1, 1, 1, 1))[:B]
+    seg = np.tile(seg_u, (reps, 1, 1, 1, 1))[:B]
+    d_img = eng.alloc(img.nbytes).upload(img)
+    d_flow = eng.alloc(flow.nbytes).upload(flow)
+    d_seg = eng.alloc(seg.nbytes).upload(seg)
+    d_pose = eng.alloc(B * 12 * 4)
+
+    def sync_all():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        eng.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.forward_device(B, d_img, d_flow, d_seg, d_pose)
+    eng.synchronize()
+
+    eng.profile(True)
+    eng.profile_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward_device(B, d_img, d_flow, d_seg, d_pose)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kernels = eng.profile_entries()
+    eng.profile(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed_max = float(t.item())
+
+    poses = d_pose.download((B, 2, 6))
+
+    # one RCCL gather of the shard poses (config 4's stitch input), outside the timed region
+    gather_ms = None
+    if world > 1:
+        mine = torch.from_numpy(poses).cuda()
+        out = [torch.empty_like(mine) for _ in range(world)]
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        dist.all_gather(out, mine)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed_max
+        n6, ms6 = kernels.get("cnv6", (0, 0.0))
+        avg6 = ms6 / max(n6, 1)
+        achieved = cnv6_flops_per_launch / (avg6 * 1e-3) / 1e12 if avg6 > 0 else 0.0
+        kern_ms = {k: round(v[1] / max(v[0], 1), 4) for k, v in kernels.items()}
+        whole = flops_per_triplet * B * args.steps / elapsed_max / 1e12
+        res = {
+            "metric": "pose-net triplets/sec (128x416x3-frame)" if (H, W) == (128, 416)
+                      else "pose-net triplets/sec (%dx%dx3-frame)" % (H, W),
+            "value": round(value, 2), "unit": "triplets/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (splitmix64 seed 8964; random-init He-uniform weights; no KITTI/ckpt offline)",
+            "config": {"workload": "BASELINE.json configs[1]: single MI355X, batch=%d synthetic %dx%d RGB+flow+seg "
+                                   "triplets, dilatedPoseNN-cnv6_128 + se_flow + fc_tanh" % (B, H, W),
+                       "version": FLAGSHIP_VERSION, "batch_per_gpu": B, "height": H, "width": W,
+                       "parallelism": "window-sharded replicas x%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32<3,1,128> (cnv6, rotation|translation fused)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(avg6, 4), "flops_per_launch": cnv6_flops_per_launch},
+            "whole_path_tflops_per_gpu": round(whole, 2),
+            "whole_path_frac_of_f32_mfma_peak": round(whole / PEAK_F32_MFMA_TFLOPS, 4),
+            "kernel_avg_ms": kern_ms,
+            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+        }
+        # parity on the bench's own batch (bounded: the first 2 windows) + CPU baseline beside it
+        from oracle import c_oracle
+        ns = min(2, B)
+        want = c_oracle.forward(cfg, img[:ns], flow[:ns], seg[:ns], weights)
+        res["max_abs_err_vs_oracle"] = float(np.abs(poses[:ns] - want).max())
+        res["max_abs_ref"] = float(np.abs(want).max())
+        res["oracle_note"] = "CPU restatement (TF1 itself cannot run offline: parity unpinned vs TF)"
+        if world == 1 and not args.no_cpu_baseline:
+            nb = max(1, min(args.cpu_sample, B))
+            cores = c_oracle.max_threads()
+            c_oracle.forward(cfg, img[:1], flow[:1], seg[:1], weights)         # warm-up
+            c0 = time.perf_counter()
+            passes = 0
+            while passes < 3 or time.perf_counter() - c0 < 10.0:
+                c_oracle.forward(cfg, img[:nb], flow[:nb], seg[:nb], weights)
+                passes += 1
+                if time.perf_counter() - c0 > 30.0:
+                    break
+            cdt = time.perf_counter() - c0
+            res["cpu_baseline"] = {"value": round(nb * passes / cdt, 3), "unit": "triplets/s", "cores": cores,
+                                   "kind": "port",
+                                   "sample": "%d passes of %d triplets (%dx%d) of the bench batch through "
+                                             "oracle/davo_oracle.c (f32, OpenMP, -O3 -march=x86-64-v3)" % (passes, nb, H, W)}
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+
+    for b in (d_img, d_flow, d_seg, d_pose):
+        b.free()
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""ctypes binding of libdavo_hip.so (include/davo_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded this module
+raises, and so does every product entry point above it."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdavo_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+EXPORTS = (
+    "davo_create", "davo_load_weight", "davo_weights_missing", "davo_forward", "davo_forward_device",
+    "davo_last_error", "davo_destroy", "davo_device_malloc", "davo_device_free", "davo_memcpy_h2d",
+    "davo_memcpy_d2h", "davo_synchronize", "davo_set_stream", "davo_profile_enable",
+    "davo_profile_reset", "davo_profile_entry", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
+)
+
+
+class DavoVariant(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("cin_per_frame", "cnv6_out", "se_act", "norm_flow",
+                                              "abs_mode", "att_source", "mask_rgb", "mask_info")]
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in ("davo_api.hip", "conv_igemm.h", "prologue.h")] + \
+           [os.path.join(INCLUDE, "davo_hip.h")]
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> davo_amd/libdavo_hip.so (in-tree, so it travels to the GPU box)."""
+    if not force and os.path.exists(LIB_PATH) and \
+            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in sources()):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-function", "-o", LIB_PATH, os.path.join(CSRC, "davo_api.hip"),
+           "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libdavo_hip.so is not built (%s missing): run `python -c 'import "
+                           "__graft_entry__ as g; g.build()'`; there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i, f32p = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)
+    L.davo_create.argtypes = [ctypes.POINTER(vp), i, i, i, i, ctypes.POINTER(DavoVariant)]
+    L.davo_load_weight.argtypes = [vp, ctypes.c_char_p, f32p, ctypes.POINTER(ctypes.c_int64), i]
+    L.davo_weights_missing.argtypes = [vp]
+    L.davo_forward.argtypes = [vp, i, vp, vp, vp, vp]
+    L.davo_forward_device.argtypes = [vp, i, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.davo_last_error.argtypes = [vp]
+    L.davo_last_error.restype = ctypes.c_char_p
+    L.davo_destroy.argtypes = [vp]
+    L.davo_destroy.restype = None
+    L.davo_device_malloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.davo_device_free.argtypes = [vp, vp]
+    L.davo_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    L.davo_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    L.davo_synchronize.argtypes = [vp]
+    L.davo_set_stream.argtypes = [vp, vp]
+    L.davo_profile_enable.argtypes = [vp, i]
+    L.davo_profile_reset.argtypes = [vp]
+    L.davo_profile_entry.argtypes = [vp, i, ctypes.c_char_p, i, ctypes.POINTER(i), ctypes.POINTER(ctypes.c_double)]
+    L.davo_set_impl.argtypes = [vp, i]
+    L.davo_debug_read.argtypes = [vp, ctypes.c_char_p, f32p, ctypes.c_size_t]
+    L.davo_conv2d_same.argtypes = [i, f32p, i, i, i, i, f32p, i, i, f32p, i, i, i, f32p, ctypes.c_char_p, i]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("davo_last_error", "davo_destroy"):
+            fn.restype = ctypes.c_int
+    _lib = L
+    return L

@@ -1,0 +1,226 @@
+// conv_igemm.h — slim.conv2d(padding='SAME') as an implicit GEMM on the gfx950 FP32 matrix
+// cores (v_mfma_f32_32x32x2_f32).  One template covers all eight PoseNN layers
+// (reference nets/posenn.py:211-215,238-240):
+//
+//     Y[m][n] = relu( sum_k A[m][k] * Wp[n][k] + bias[n] )
+//       m = (image, oy, ox) flattened over the whole batch     (GEMM M)
+//       n = output channel                                      (GEMM N)
+//       k = (tap, ci), tap = ky*KS+kx, ci < Cin (power of two)   (GEMM K, padded to 32)
+//
+// A is never materialised: a k-chunk of 32 is one (or several, when Cin < 32) filter taps
+// of contiguous NHWC channels, gathered straight from the input activation with TF's
+// asymmetric SAME padding turned into a bounds test (zero fill).  Weights are re-laid-out
+// once at load time to Wp[Cout_pad][K_pad] (k contiguous) so both operands are staged with
+// the same 16-byte rows.
+//
+// Tile: 128 (M) x BN (N) per 256-thread workgroup (4 waves, one per SIMD), K step 32,
+// LDS double-buffered with one barrier per step; rows padded to 36 floats so the
+// ds_read_b128 fragment reads are bank-conflict free (36 = 4*9, 9 odd -> 16 distinct slots).
+// Each lane reads 4 consecutive k of its row with one ds_read_b128 and feeds them to four
+// successive MFMAs (lane half h supplies k = 8g+4h+j to MFMA j of group g for both operands,
+// so A and B agree on the contraction order).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace davo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+    const float* x;       // input activation, pixel-major NHWC
+    const float* w;       // packed weights [Npad][Kpad]
+    const float* bias;    // [Npad]
+    float* y;             // output activation
+    const float* zeros;   // >= 16 bytes of zeros: what a padded (out-of-image) tap reads
+    int Hin, Win, Hout, Wout;
+    int cin_log2;         // Cin = 1 << cin_log2 (channels per tap in the packed k order)
+    int x_ld, x_coff;     // floats per input pixel, first channel used
+    int y_ld, y_coff;     // floats per output pixel, first channel written
+    int Cout;             // valid output channels (per group)
+    int pad_t, pad_l, rate;
+    int M;                // images * Hout * Wout
+    int nchunks, Kpad, ntaps;
+    int ntiles_n;
+    int relu;
+    // grouped launch (blockIdx.y = group): per-group strides
+    int g_x_coff, g_y_coff;
+    long g_w, g_bias;
+};
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDK = 36;          // padded LDS row (floats)
+
+template <int BN> struct Tile {
+    static constexpr int WN = BN >= 64 ? 2 : 1;    // waves along N
+    static constexpr int WM = 4 / WN;              // waves along M
+    static constexpr int TM = BM / WM / 32;        // 32x32 MFMA tiles per wave along M
+    static constexpr int TN = BN / WN / 32;
+    static constexpr int NB_LOADS = BN / 32;       // float4 weight loads per thread per chunk
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDK * 4;
+};
+
+// XCD-aware, bijective remap of the linear workgroup id: workgroups b, b+8, b+16, ... share an
+// XCD (and its 4 MiB L2), so give each XCD a contiguous run of tiles = neighbouring pixels of
+// the same images, whose dilated taps overlap.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + (bid >> 3);
+}
+
+template <int KS, int STRIDE, int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
+    using T = Tile<BN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wid / T::WN, wn = wid % T::WN;
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = tile % p.ntiles_n, mtile = tile / p.ntiles_n;
+    const int grp = blockIdx.y;
+    const float* __restrict__ xg = p.x + p.x_coff + grp * p.g_x_coff;
+    const float* __restrict__ wg = p.w + grp * p.g_w + (long)ntile * BN * p.Kpad;
+    const float* __restrict__ bg = p.bias + grp * p.g_bias + ntile * BN;
+    float* __restrict__ yg = p.y + p.y_coff + grp * p.g_y_coff;
+
+    // ---- staging assignment: thread -> (row r0+32j, 4 consecutive k at kk) ---------------
+    const int r0 = tid >> 3, kk = (tid & 7) * 4;
+    int iy0[4], ix0[4], pix0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = mtile * BM + r0 + 32 * j;
+        if (m < p.M) {
+            const int hw = p.Hout * p.Wout;
+            const int n = m / hw, rem = m - n * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            iy0[j] = oy * STRIDE - p.pad_t;
+            ix0[j] = ox * STRIDE - p.pad_l;
+            pix0[j] = n * p.Hin * p.Win;
+        } else {
+            iy0[j] = -(1 << 28);               // every tap lands out of bounds -> zero rows
+            ix0[j] = 0;
+            pix0[j] = 0;
+        }
+    }
+    const int cmask = (1 << p.cin_log2) - 1;
+
+    // Staging registers are named scalars, not arrays: hipcc (ROCm 7.2) keeps a conditionally
+    // written float4 array in scratch and serialises every load behind a scratch store.
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define DAVO_LOAD_A(j_, dst_)                                                                      \
+    {                                                                                              \
+        const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
+        const bool ok = tap_ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win; \
+        const long off = (long)(pix0[j_] + iy * p.Win + ix) * p.x_ld + c;                          \
+        /* unconditional load; a padded tap reads a zero line: no branch around the load */       \
+        dst_ = *reinterpret_cast<const float4*>(ok ? xg + off : p.zeros);                          \
+    }
+#define DAVO_LOAD_CHUNK(q_)                                                                        \
+    {                                                                                              \
+        const int kg = (q_) * BK + kk;                                                             \
+        const int tap = kg >> p.cin_log2, c = kg & cmask;                                          \
+        const int ky = tap / KS, kx = tap - ky * KS;                                               \
+        const int dy = ky * p.rate, dx = kx * p.rate;                                              \
+        const bool tap_ok = tap < p.ntaps;                                                         \
+        DAVO_LOAD_A(0, ra0) DAVO_LOAD_A(1, ra1) DAVO_LOAD_A(2, ra2) DAVO_LOAD_A(3, ra3)            \
+        const float* wrow = wg + (long)r0 * p.Kpad + kg;                                           \
+        rb0 = *reinterpret_cast<const float4*>(wrow);                                              \
+        if constexpr (T::NB_LOADS > 1) rb1 = *reinterpret_cast<const float4*>(wrow + 32L * p.Kpad); \
+        if constexpr (T::NB_LOADS > 2) {                                                           \
+            rb2 = *reinterpret_cast<const float4*>(wrow + 64L * p.Kpad);                           \
+            rb3 = *reinterpret_cast<const float4*>(wrow + 96L * p.Kpad);                           \
+        }                                                                                          \
+    }
+#define DAVO_STORE_CHUNK(buf_)                                                                     \
+    {                                                                                              \
+        float* a_ = As + (buf_) * BM * LDK + r0 * LDK + kk;                                        \
+        float* b_ = Bs + (buf_) * BN * LDK + r0 * LDK + kk;                                        \
+        *reinterpret_cast<float4*>(a_) = ra0;                                                      \
+        *reinterpret_cast<float4*>(a_ + 32 * LDK) = ra1;                                           \
+        *reinterpret_cast<float4*>(a_ + 64 * LDK) = ra2;                                           \
+        *reinterpret_cast<float4*>(a_ + 96 * LDK) = ra3;                                           \
+        *reinterpret_cast<float4*>(b_) = rb0;                                                      \
+        if constexpr (T::NB_LOADS > 1) *reinterpret_cast<float4*>(b_ + 32 * LDK) = rb1;            \
+        if constexpr (T::NB_LOADS > 2) {                                                           \
+            *reinterpret_cast<float4*>(b_ + 64 * LDK) = rb2;                                       \
+            *reinterpret_cast<float4*>(b_ + 96 * LDK) = rb3;                                       \
+        }                                                                                          \
+    }
+
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    DAVO_LOAD_CHUNK(0)
+    DAVO_STORE_CHUNK(0)
+    __syncthreads();
+
+#define DAVO_COMPUTE(buf_)                                                                         \
+    {                                                                                              \
+        const float* a = As + (buf_) * BM * LDK + (wm * T::TM * 32 + li) * LDK + 4 * lh;           \
+        const float* b = Bs + (buf_) * BN * LDK + (wn * T::TN * 32 + li) * LDK + 4 * lh;           \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
+            float4 fa[T::TM], fb[T::TN];                                                           \
+            _Pragma("unroll") for (int i = 0; i < T::TM; ++i)                                      \
+                fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDK + g * 8);                \
+            _Pragma("unroll") for (int j = 0; j < T::TN; ++j)                                      \
+                fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDK + g * 8);                \
+            _Pragma("unroll") for (int i = 0; i < T::TM; ++i)                                      \
+                _Pragma("unroll") for (int j = 0; j < T::TN; ++j) {                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0); \
+                }                                                                                  \
+        }                                                                                          \
+    }
+
+    for (int q = 0; q + 1 < p.nchunks; ++q) {
+        const int buf = q & 1;
+        DAVO_LOAD_CHUNK(q + 1)                           // global loads fly under the MFMAs
+        __builtin_amdgcn_sched_barrier(0);               // keep hipcc from sinking them to the stores
+        DAVO_COMPUTE(buf)
+        __builtin_amdgcn_sched_barrier(0);
+        DAVO_STORE_CHUNK(buf ^ 1)
+        __syncthreads();
+    }
+    DAVO_COMPUTE((p.nchunks - 1) & 1)
+
+    // ---- epilogue: bias + ReLU, C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int ncol = wn * T::TN * 32 + j * 32 + li;          // column inside the N tile
+        const int n = ntile * BN + ncol;
+        const float bv = bg[ncol];
+        const bool n_ok = n < p.Cout;
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * T::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = mtile * BM + row;
+                float v = acc[i][j][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (n_ok && m < p.M) yg[(long)m * p.y_ld + n] = v;
+            }
+    }
+}
+
+#undef DAVO_LOAD_A
+#undef DAVO_LOAD_CHUNK
+#undef DAVO_STORE_CHUNK
+#undef DAVO_COMPUTE
+
+}  // namespace davo

@@ -1,0 +1,777 @@
+// davo_api.hip — C ABI of libdavo_hip.so (see include/davo_hip.h) and the host-side launch
+// plan of the pose path:
+//
+//   se_squeeze_partial -> se_excite -> mask_pack -> cnv1..cnv5 -> cnv6 (rotation|translation
+//   fused into one N = 2*cnv6_out GEMM, both read cnv5: nets/posenn.py:222-238)
+//   -> cnv7 (grouped x2) -> pose_head.
+//
+// The two PoseNN calls of a triplet (davo.py:1456-1457, shared weights) run as one batch of
+// 2B pair images.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/davo_hip.h"
+#include "conv_igemm.h"
+#include "prologue.h"
+
+using namespace davo;
+
+namespace {
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    float* dev = nullptr;          // raw copy in the reference layout (impl 1, pose_head, SE)
+};
+
+struct ConvLayer {
+    const char* label;
+    int KS, stride, rate;
+    int cin, cin_log2, cout;       // packed input channels per tap (power of two), valid outputs
+    int BN, npad, kpad, nchunks, groups;
+    float* d_w = nullptr;          // [groups][npad][kpad]
+    float* d_b = nullptr;          // [groups][npad]
+};
+
+struct ProfEntry {
+    std::string name;
+    int launches = 0;
+    double total_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+void same_pad(int in, int k, int stride, int rate, int* out, int* before) {
+    const int o = (in + stride - 1) / stride;
+    const int keff = (k - 1) * rate + 1;
+    int total = (o - 1) * stride + keff - in;
+    if (total < 0) total = 0;
+    *out = o;
+    *before = total / 2;
+}
+
+int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+}  // namespace
+
+struct davo_ctx {
+    int device = 0, H = 0, W = 0, max_batch = 0;
+    Variant v{};
+    int impl = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    std::map<std::string, HostTensor> weights;
+    std::vector<std::string> needed;
+    bool packed_ready = false;
+    ConvLayer L[7];                            // cnv1..cnv5, cnv6 (fused), cnv7 (grouped)
+    float *d_wpred = nullptr, *d_bpred = nullptr;
+    // geometry
+    int H1, W1, H2, W2, H3, W3;
+    // workspace
+    float *d_partial = nullptr, *d_tab = nullptr, *d_packed = nullptr, *d_zeros = nullptr;
+    float* d_act[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t act_floats_per_img[7];
+    int act_ch[7];
+    int packed_ld = 8;
+    int last_B = 0;
+    // host-API staging
+    void *s_img = nullptr, *s_flow = nullptr, *s_seg = nullptr, *s_pose = nullptr;
+    // profiling
+    bool prof = false;
+    std::vector<ProfEntry> prof_entries;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(davo_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(c, DAVO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// ---- conv dispatch ----------------------------------------------------------------------
+template <int KS, int STRIDE, int BN>
+hipError_t launch_conv_t(const ConvParams& p, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = conv_igemm_f32<KS, STRIDE, BN>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Tile<BN>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), Tile<BN>::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+template <int KS, int STRIDE>
+hipError_t launch_conv_bn(int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
+    switch (BN) {
+        case 32: return launch_conv_t<KS, STRIDE, 32>(p, grid, s);
+        case 64: return launch_conv_t<KS, STRIDE, 64>(p, grid, s);
+        case 128: return launch_conv_t<KS, STRIDE, 128>(p, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv(int KS, int stride, int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
+    if (stride == 1) {
+        switch (KS) {
+            case 1: return launch_conv_bn<1, 1>(BN, p, grid, s);
+            case 3: return launch_conv_bn<3, 1>(BN, p, grid, s);
+            case 5: return launch_conv_bn<5, 1>(BN, p, grid, s);
+            case 7: return launch_conv_bn<7, 1>(BN, p, grid, s);
+        }
+    } else if (stride == 2) {
+        switch (KS) {
+            case 1: return launch_conv_bn<1, 2>(BN, p, grid, s);
+            case 3: return launch_conv_bn<3, 2>(BN, p, grid, s);
+            case 5: return launch_conv_bn<5, 2>(BN, p, grid, s);
+            case 7: return launch_conv_bn<7, 2>(BN, p, grid, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+int pick_bn(int cout) { return cout <= 32 ? 32 : (cout % 128 == 0 ? 128 : (cout <= 64 ? 64 : 128)); }
+
+// Re-lay-out HWIO weights [KS,KS,Cin_tf,Cout] -> Wp[npad][kpad], k = tap*cin_packed + c, where
+// packed channel c reads TF input channel chmap[c] (or nothing: -1).  Zero padded.
+void pack_conv_weights(const float* w_tf, int KS, int cin_tf, int cout, const int* chmap, int cin_packed,
+                       int npad, int kpad, float* out /*npad*kpad, zeroed*/) {
+    for (int tap = 0; tap < KS * KS; ++tap)
+        for (int c = 0; c < cin_packed; ++c) {
+            const int ci = chmap ? chmap[c] : c;
+            if (ci < 0 || ci >= cin_tf) continue;
+            const float* src = w_tf + ((size_t)tap * cin_tf + ci) * cout;
+            const size_t k = (size_t)tap * cin_packed + c;
+            for (int n = 0; n < cout; ++n) out[(size_t)n * kpad + k] = src[n];
+        }
+}
+
+// ---- profiling --------------------------------------------------------------------------
+struct ProfScope {
+    davo_ctx* c;
+    ProfEntry* e = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(davo_ctx* ctx, const char* name) : c(ctx) {
+        if (!c->prof) return;
+        for (auto& pe : c->prof_entries)
+            if (pe.name == name) { e = &pe; break; }
+        if (!e) {
+            c->prof_entries.emplace_back();
+            e = &c->prof_entries.back();
+            e->name = name;
+        }
+        auto get = [&]() {
+            hipEvent_t ev = nullptr;
+            if (!c->event_pool.empty()) { ev = c->event_pool.back(); c->event_pool.pop_back(); }
+            else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+            return ev;
+        };
+        a = get(); b = get();
+        if (a) (void)hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (!e) return;
+        if (b) (void)hipEventRecord(b, c->stream);
+        if (a && b) e->pending.emplace_back(a, b);
+    }
+};
+
+int prof_collect(davo_ctx* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& pe : c->prof_entries) {
+        for (auto& ab : pe.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ab.first, ab.second) == hipSuccess) {
+                pe.total_ms += ms;
+                pe.launches += 1;
+            }
+            c->event_pool.push_back(ab.first);
+            c->event_pool.push_back(ab.second);
+        }
+        pe.pending.clear();
+    }
+    return DAVO_OK;
+}
+
+// ---- weights ----------------------------------------------------------------------------
+std::vector<std::string> needed_names(const Variant& v) {
+    std::vector<std::string> n;
+    const char* trunk[] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5"};
+    for (auto l : trunk) {
+        n.push_back(std::string("pose_exp_net/") + l + "/weights");
+        n.push_back(std::string("pose_exp_net/") + l + "/biases");
+    }
+    const char* heads[] = {"rotation", "translation"};
+    const char* hl[] = {"cnv6", "cnv7", "pred"};
+    for (auto h : heads)
+        for (auto l : hl) {
+            n.push_back(std::string("pose_exp_net/pose/") + h + "/" + l + "/weights");
+            n.push_back(std::string("pose_exp_net/pose/") + h + "/" + l + "/biases");
+        }
+    if (v.att_source == 1) {
+        n.push_back("pose_exp_net/se_flow/bottleneck_fc/kernel");
+        n.push_back("pose_exp_net/se_flow/bottleneck_fc/bias");
+        n.push_back("pose_exp_net/se_flow/recover_fc/kernel");
+        n.push_back("pose_exp_net/se_flow/recover_fc/bias");
+    } else if (v.att_source == 2 || v.att_source == 3) {
+        n.push_back("pose_exp_net/pose_exp_net/seg_channel_weight/weight");
+    }
+    return n;
+}
+
+bool expected_shape(const davo_ctx* c, const std::string& name, std::vector<int64_t>* sh) {
+    const int c10 = 2 * c->v.cin_per_frame, c6 = c->v.cnv6_out;
+    auto is = [&](const char* s) { return name == s; };
+    auto ends = [&](const char* s) {
+        const size_t n = strlen(s);
+        return name.size() >= n && name.compare(name.size() - n, n, s) == 0;
+    };
+    if (is("pose_exp_net/cnv1/weights")) *sh = {7, 7, c10, 16};
+    else if (is("pose_exp_net/cnv1/biases")) *sh = {16};
+    else if (is("pose_exp_net/cnv2/weights")) *sh = {5, 5, 16, 32};
+    else if (is("pose_exp_net/cnv2/biases")) *sh = {32};
+    else if (is("pose_exp_net/cnv3/weights")) *sh = {3, 3, 32, 64};
+    else if (is("pose_exp_net/cnv3/biases")) *sh = {64};
+    else if (is("pose_exp_net/cnv4/weights")) *sh = {3, 3, 64, 128};
+    else if (is("pose_exp_net/cnv4/biases")) *sh = {128};
+    else if (is("pose_exp_net/cnv5/weights")) *sh = {3, 3, 128, 256};
+    else if (is("pose_exp_net/cnv5/biases")) *sh = {256};
+    else if (ends("/cnv6/weights")) *sh = {3, 3, 256, c6};
+    else if (ends("/cnv6/biases")) *sh = {c6};
+    else if (ends("/cnv7/weights")) *sh = {3, 3, c6, 256};
+    else if (ends("/cnv7/biases")) *sh = {256};
+    else if (ends("/pred/weights")) *sh = {1, 1, 256, 3};
+    else if (ends("/pred/biases")) *sh = {3};
+    else if (is("pose_exp_net/se_flow/bottleneck_fc/kernel")) *sh = {2, 8};
+    else if (is("pose_exp_net/se_flow/bottleneck_fc/bias")) *sh = {8};
+    else if (is("pose_exp_net/se_flow/recover_fc/kernel")) *sh = {8, NCLS};
+    else if (is("pose_exp_net/se_flow/recover_fc/bias")) *sh = {NCLS};
+    else if (is("pose_exp_net/pose_exp_net/seg_channel_weight/weight")) *sh = {NCLS};
+    else return false;
+    return true;
+}
+
+int upload(davo_ctx* c, const std::vector<float>& host, float** dev) {
+    if (*dev) { HIP_TRY(c, hipFree(*dev)); *dev = nullptr; }
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(dev), host.size() * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return DAVO_OK;
+}
+
+void init_layer(ConvLayer& L, const char* label, int KS, int stride, int rate, int cin, int cout, int groups) {
+    L.label = label; L.KS = KS; L.stride = stride; L.rate = rate;
+    L.cin = cin; L.cin_log2 = ilog2_exact(cin); L.cout = cout; L.groups = groups;
+    L.BN = pick_bn(cout);
+    L.npad = (cout + L.BN - 1) / L.BN * L.BN;
+    L.kpad = (KS * KS * cin + BK - 1) / BK * BK;
+    L.nchunks = L.kpad / BK;
+}
+
+int build_packed_weights(davo_ctx* c) {
+    const int c6 = c->v.cnv6_out, cpf = c->v.cin_per_frame;
+    auto W = [&](const std::string& n) -> const HostTensor& { return c->weights.at(n); };
+    // cnv1: packed input channel -> TF input channel.  v1: [t r,g,b | 0,0 | s r,g,b | fx,fy];
+    // the two zero channels (davo.py:979,1065) are dropped.  v0: [t rgb | s rgb].
+    int chmap1[8];
+    if (cpf == 5) { const int m[8] = {0, 1, 2, 5, 6, 7, 8, 9}; memcpy(chmap1, m, sizeof m); }
+    else { const int m[8] = {0, 1, 2, 3, 4, 5, -1, -1}; memcpy(chmap1, m, sizeof m); }
+
+    struct Src { const char* w; const char* b; const int* chmap; int cin_tf; };
+    const Src trunk[5] = {{"pose_exp_net/cnv1/weights", "pose_exp_net/cnv1/biases", chmap1, 2 * cpf},
+                          {"pose_exp_net/cnv2/weights", "pose_exp_net/cnv2/biases", nullptr, 16},
+                          {"pose_exp_net/cnv3/weights", "pose_exp_net/cnv3/biases", nullptr, 32},
+                          {"pose_exp_net/cnv4/weights", "pose_exp_net/cnv4/biases", nullptr, 64},
+                          {"pose_exp_net/cnv5/weights", "pose_exp_net/cnv5/biases", nullptr, 128}};
+    for (int i = 0; i < 5; ++i) {
+        ConvLayer& L = c->L[i];
+        std::vector<float> wp((size_t)L.npad * L.kpad, 0.f), bp(L.npad, 0.f);
+        pack_conv_weights(W(trunk[i].w).data.data(), L.KS, trunk[i].cin_tf, L.cout, trunk[i].chmap, L.cin,
+                          L.npad, L.kpad, wp.data());
+        memcpy(bp.data(), W(trunk[i].b).data.data(), L.cout * sizeof(float));
+        int rc = upload(c, wp, &L.d_w); if (rc) return rc;
+        rc = upload(c, bp, &L.d_b); if (rc) return rc;
+    }
+    const char* heads[2] = {"rotation", "translation"};
+    {   // cnv6: one GEMM, N = [rotation c6 | translation c6]
+        ConvLayer& L = c->L[5];
+        std::vector<float> wp((size_t)L.npad * L.kpad, 0.f), bp(L.npad, 0.f);
+        for (int h = 0; h < 2; ++h) {
+            const std::string p = std::string("pose_exp_net/pose/") + heads[h] + "/cnv6/";
+            pack_conv_weights(W(p + "weights").data.data(), 3, 256, c6, nullptr, 256, c6, L.kpad,
+                              wp.data() + (size_t)h * c6 * L.kpad);
+            memcpy(bp.data() + h * c6, W(p + "biases").data.data(), c6 * sizeof(float));
+        }
+        int rc = upload(c, wp, &L.d_w); if (rc) return rc;
+        rc = upload(c, bp, &L.d_b); if (rc) return rc;
+    }
+    {   // cnv7: two groups (blockIdx.y), group g reads cnv6 channels [g*c6, (g+1)*c6)
+        ConvLayer& L = c->L[6];
+        std::vector<float> wp((size_t)2 * L.npad * L.kpad, 0.f), bp((size_t)2 * L.npad, 0.f);
+        for (int h = 0; h < 2; ++h) {
+            const std::string p = std::string("pose_exp_net/pose/") + heads[h] + "/cnv7/";
+            pack_conv_weights(W(p + "weights").data.data(), 3, c6, 256, nullptr, c6, L.npad, L.kpad,
+                              wp.data() + (size_t)h * L.npad * L.kpad);
+            memcpy(bp.data() + (size_t)h * L.npad, W(p + "biases").data.data(), 256 * sizeof(float));
+        }
+        int rc = upload(c, wp, &L.d_w); if (rc) return rc;
+        rc = upload(c, bp, &L.d_b); if (rc) return rc;
+    }
+    {   // pred: [2][256][3] + [2][3]
+        std::vector<float> wp(2 * 256 * 3), bp(2 * 3);
+        for (int h = 0; h < 2; ++h) {
+            const std::string p = std::string("pose_exp_net/pose/") + heads[h] + "/pred/";
+            memcpy(wp.data() + h * 768, W(p + "weights").data.data(), 768 * sizeof(float));
+            memcpy(bp.data() + h * 3, W(p + "biases").data.data(), 3 * sizeof(float));
+        }
+        int rc = upload(c, wp, &c->d_wpred); if (rc) return rc;
+        rc = upload(c, bp, &c->d_bpred); if (rc) return rc;
+    }
+    c->packed_ready = true;
+    return DAVO_OK;
+}
+
+int missing_weights(davo_ctx* c, std::string* names) {
+    int n = 0;
+    for (auto& nm : c->needed)
+        if (!c->weights.count(nm)) {
+            ++n;
+            if (names) { if (!names->empty()) *names += ", "; *names += nm; }
+        }
+    return n;
+}
+
+// ---- the forward plan -------------------------------------------------------------------
+int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int Win, float* y, int y_ld,
+                   int NB) {
+    const ConvLayer& L = c->L[li];
+    ConvParams p{};
+    int Ho, Wo, pt, pl;
+    same_pad(Hin, L.KS, L.stride, L.rate, &Ho, &pt);
+    same_pad(Win, L.KS, L.stride, L.rate, &Wo, &pl);
+    p.x = x; p.w = L.d_w; p.bias = L.d_b; p.y = y; p.zeros = c->d_zeros;
+    p.Hin = Hin; p.Win = Win; p.Hout = Ho; p.Wout = Wo;
+    p.cin_log2 = L.cin_log2; p.x_ld = x_ld; p.x_coff = 0; p.y_ld = y_ld; p.y_coff = 0;
+    p.Cout = L.cout; p.pad_t = pt; p.pad_l = pl; p.rate = L.rate;
+    p.M = NB * Ho * Wo; p.nchunks = L.nchunks; p.Kpad = L.kpad; p.ntaps = L.KS * L.KS;
+    p.ntiles_n = L.npad / L.BN; p.relu = 1;
+    if (L.groups == 2) {
+        p.g_x_coff = L.cin; p.g_y_coff = L.cout;
+        p.g_w = (long)L.npad * L.kpad; p.g_bias = L.npad;
+    }
+    const int mtiles = (p.M + BM - 1) / BM;
+    dim3 grid(mtiles * p.ntiles_n, L.groups);
+    ProfScope ps(c, L.label);
+    HIP_TRY(c, launch_conv(L.KS, L.stride, L.BN, p, grid, c->stream));
+    return DAVO_OK;
+}
+
+int run_direct(davo_ctx* c, const char* label, const float* x, int N, int Hin, int Win, int cin, int x_ld,
+               int x_coff, const std::string& wname, const std::string& bname, int KS, int cout, int stride,
+               int rate, float* y, int y_ld, int y_coff) {
+    int Ho, Wo, pt, pl;
+    same_pad(Hin, KS, stride, rate, &Ho, &pt);
+    same_pad(Win, KS, stride, rate, &Wo, &pl);
+    const long total = (long)N * Ho * Wo * cout;
+    ProfScope ps(c, label);
+    hipLaunchKernelGGL(conv_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, x, N, Hin,
+                       Win, cin, x_ld, x_coff, c->weights.at(wname).dev, KS, cout, c->weights.at(bname).dev,
+                       stride, rate, pt, pl, Ho, Wo, 1, y, y_ld, y_coff);
+    HIP_TRY(c, hipGetLastError());
+    return DAVO_OK;
+}
+
+int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, void* d_pose) {
+    if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
+    if (!d_img || !d_flow || !d_seg || !d_pose) return fail(c, DAVO_ERR_INVALID, "null device pointer");
+    {
+        std::string names;
+        if (missing_weights(c, &names)) return fail(c, DAVO_ERR_NOT_READY, "weights not loaded: %s", names.c_str());
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->packed_ready) { int rc = build_packed_weights(c); if (rc) return rc; }
+    const int H = c->H, W = c->W, HW = H * W, NB = 2 * B;
+    const Variant& v = c->v;
+    hipStream_t s = c->stream;
+    auto wdev = [&](const char* n) -> const float* {
+        auto it = c->weights.find(n);
+        return it == c->weights.end() ? nullptr : it->second.dev;
+    };
+    if (v.att_source == 1) {
+        ProfScope ps(c, "se_squeeze_partial");
+        hipLaunchKernelGGL(se_squeeze_partial, dim3(SQ_CHUNKS, 2, B), dim3(256), 0, s,
+                           static_cast<const float*>(d_flow), HW, v.norm_flow, v.abs_mode, c->d_partial);
+        HIP_TRY(c, hipGetLastError());
+    }
+    {
+        ProfScope ps(c, "se_excite");
+        hipLaunchKernelGGL(se_excite, dim3(B), dim3(64), 0, s, c->d_partial, HW, v,
+                           wdev("pose_exp_net/se_flow/bottleneck_fc/kernel"), wdev("pose_exp_net/se_flow/bottleneck_fc/bias"),
+                           wdev("pose_exp_net/se_flow/recover_fc/kernel"), wdev("pose_exp_net/se_flow/recover_fc/bias"),
+                           wdev("pose_exp_net/pose_exp_net/seg_channel_weight/weight"), c->d_tab);
+        HIP_TRY(c, hipGetLastError());
+    }
+    const long nthreads = (long)NB * H * (W / 4);
+    c->packed_ld = c->impl == 0 ? 8 : 10;
+    {
+        ProfScope ps(c, "mask_pack");
+        if (c->impl == 0)
+            hipLaunchKernelGGL(mask_pack<8>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s,
+                               static_cast<const uint8_t*>(d_img), static_cast<const float*>(d_flow),
+                               static_cast<const float*>(d_seg), c->d_tab, v, B, H, W, c->d_packed);
+        else
+            hipLaunchKernelGGL(mask_pack<10>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s,
+                               static_cast<const uint8_t*>(d_img), static_cast<const float*>(d_flow),
+                               static_cast<const float*>(d_seg), c->d_tab, v, B, H, W, c->d_packed);
+        HIP_TRY(c, hipGetLastError());
+    }
+    const int c6 = v.cnv6_out;
+    float** a = c->d_act;
+    int rc;
+    if (c->impl == 0) {
+        if ((rc = run_conv_layer(c, 0, c->d_packed, 8, H, W, a[0], 16, NB))) return rc;
+        if ((rc = run_conv_layer(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, NB))) return rc;
+        if ((rc = run_conv_layer(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, NB))) return rc;
+        if ((rc = run_conv_layer(c, 3, a[2], 64, c->H2, c->W2, a[3], 128, NB))) return rc;
+        if ((rc = run_conv_layer(c, 4, a[3], 128, c->H2, c->W2, a[4], 256, NB))) return rc;
+        if ((rc = run_conv_layer(c, 5, a[4], 256, c->H2, c->W2, a[5], 2 * c6, NB))) return rc;
+        if ((rc = run_conv_layer(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, NB))) return rc;
+    } else {
+        const std::string P = "pose_exp_net/";
+        const int c10 = 2 * v.cin_per_frame;
+        if (v.cin_per_frame != 5) return fail(c, DAVO_ERR_INVALID, "impl 1 supports the 10-channel (v1) input only");
+        if ((rc = run_direct(c, "cnv1", c->d_packed, NB, H, W, c10, 10, 0, P + "cnv1/weights", P + "cnv1/biases", 7, 16, 2, 1, a[0], 16, 0))) return rc;
+        if ((rc = run_direct(c, "cnv2", a[0], NB, c->H1, c->W1, 16, 16, 0, P + "cnv2/weights", P + "cnv2/biases", 5, 32, 2, 1, a[1], 32, 0))) return rc;
+        if ((rc = run_direct(c, "cnv3", a[1], NB, c->H2, c->W2, 32, 32, 0, P + "cnv3/weights", P + "cnv3/biases", 3, 64, 1, 2, a[2], 64, 0))) return rc;
+        if ((rc = run_direct(c, "cnv4", a[2], NB, c->H2, c->W2, 64, 64, 0, P + "cnv4/weights", P + "cnv4/biases", 3, 128, 1, 4, a[3], 128, 0))) return rc;
+        if ((rc = run_direct(c, "cnv5", a[3], NB, c->H2, c->W2, 128, 128, 0, P + "cnv5/weights", P + "cnv5/biases", 3, 256, 1, 8, a[4], 256, 0))) return rc;
+        const char* heads[2] = {"rotation", "translation"};
+        for (int h = 0; h < 2; ++h) {
+            const std::string hp = P + "pose/" + heads[h] + "/";
+            if ((rc = run_direct(c, "cnv6", a[4], NB, c->H2, c->W2, 256, 256, 0, hp + "cnv6/weights", hp + "cnv6/biases", 3, c6, 1, 2, a[5], 2 * c6, h * c6))) return rc;
+            if ((rc = run_direct(c, "cnv7", a[5], NB, c->H2, c->W2, c6, 2 * c6, h * c6, hp + "cnv7/weights", hp + "cnv7/biases", 3, 256, 2, 1, a[6], 512, h * 256))) return rc;
+        }
+    }
+    {
+        ProfScope ps(c, "pose_head");
+        hipLaunchKernelGGL(pose_head, dim3(NB, 2), dim3(256), 0, s, a[6], c->H3 * c->W3, c->d_wpred, c->d_bpred,
+                           static_cast<float*>(d_pose));
+        HIP_TRY(c, hipGetLastError());
+    }
+    c->last_B = B;
+    return DAVO_OK;
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const davo_variant* v) {
+    if (!out || !v) return DAVO_ERR_INVALID;
+    *out = nullptr;
+    davo_ctx* c = new davo_ctx();
+    *out = c;                                   // returned even on failure so the message is readable
+    c->device = device; c->H = H; c->W = W; c->max_batch = max_batch;
+    c->v = Variant{v->cin_per_frame, v->cnv6_out, v->se_act, v->norm_flow, v->abs_mode, v->att_source,
+                   v->mask_rgb, v->mask_info};
+    if (H < 16 || W < 16 || H % 4 || W % 4) return fail(c, DAVO_ERR_INVALID, "H and W must be multiples of 4 and >= 16 (got %dx%d)", H, W);
+    if (max_batch < 1) return fail(c, DAVO_ERR_INVALID, "max_batch must be >= 1");
+    if (v->cin_per_frame != 5 && v->cin_per_frame != 3) return fail(c, DAVO_ERR_INVALID, "cin_per_frame must be 3 or 5");
+    if (ilog2_exact(v->cnv6_out) < 5 || v->cnv6_out > 256) return fail(c, DAVO_ERR_INVALID, "cnv6_out must be 32, 64, 128 or 256");
+    if (v->se_act < 0 || v->se_act > 2 || v->abs_mode < 0 || v->abs_mode > 3 || v->att_source < 0 || v->att_source > 3)
+        return fail(c, DAVO_ERR_INVALID, "variant field out of range");
+    int ndev = 0;
+    HIP_TRY(c, hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(c, DAVO_ERR_INVALID, "device %d not present (%d visible)", device, ndev);
+    HIP_TRY(c, hipSetDevice(device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    c->needed = needed_names(c->v);
+
+    c->H1 = (H + 1) / 2; c->W1 = (W + 1) / 2;
+    c->H2 = (c->H1 + 1) / 2; c->W2 = (c->W1 + 1) / 2;
+    c->H3 = (c->H2 + 1) / 2; c->W3 = (c->W2 + 1) / 2;
+    const int c6 = c->v.cnv6_out;
+    init_layer(c->L[0], "cnv1", 7, 2, 1, 8, 16, 1);
+    init_layer(c->L[1], "cnv2", 5, 2, 1, 16, 32, 1);
+    init_layer(c->L[2], "cnv3", 3, 1, 2, 32, 64, 1);
+    init_layer(c->L[3], "cnv4", 3, 1, 4, 64, 128, 1);
+    init_layer(c->L[4], "cnv5", 3, 1, 8, 128, 256, 1);
+    init_layer(c->L[5], "cnv6", 3, 1, 2, 256, 2 * c6, 1);
+    init_layer(c->L[6], "cnv7", 3, 2, 1, c6, 256, 2);
+
+    const size_t NB = 2 * (size_t)max_batch;
+    const int ch[7] = {16, 32, 64, 128, 256, 2 * c6, 512};
+    const size_t px[7] = {(size_t)c->H1 * c->W1, (size_t)c->H2 * c->W2, (size_t)c->H2 * c->W2, (size_t)c->H2 * c->W2,
+                          (size_t)c->H2 * c->W2, (size_t)c->H2 * c->W2, (size_t)c->H3 * c->W3};
+    for (int i = 0; i < 7; ++i) {
+        c->act_ch[i] = ch[i];
+        c->act_floats_per_img[i] = px[i] * ch[i];
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_act[i]), NB * c->act_floats_per_img[i] * sizeof(float)));
+    }
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_packed), NB * (size_t)H * W * 10 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_partial), (size_t)max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_tab), (size_t)max_batch * 3 * NCLS * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_zeros), 256));
+    HIP_TRY(c, hipMemset(c->d_zeros, 0, 256));
+    HIP_TRY(c, hipMemset(c->d_partial, 0, (size_t)max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
+    return DAVO_OK;
+}
+
+int davo_load_weight(davo_ctx* c, const char* tf_name, const float* data, const int64_t* shape, int ndim) {
+    if (!c || !tf_name || !data || !shape || ndim < 1 || ndim > 4) return fail(c, DAVO_ERR_INVALID, "bad argument to davo_load_weight");
+    std::vector<int64_t> want;
+    if (!expected_shape(c, tf_name, &want)) return fail(c, DAVO_ERR_INVALID, "unknown variable `%s'", tf_name);
+    bool listed = false;
+    for (auto& n : c->needed) listed |= (n == tf_name);
+    if (!listed) return fail(c, DAVO_ERR_INVALID, "variable `%s' is not part of this variant", tf_name);
+    std::vector<int64_t> got(shape, shape + ndim);
+    if (got != want) {
+        std::string g, w;
+        for (auto d : got) g += std::to_string(d) + ",";
+        for (auto d : want) w += std::to_string(d) + ",";
+        return fail(c, DAVO_ERR_INVALID, "`%s': shape [%s] does not match expected [%s]", tf_name, g.c_str(), w.c_str());
+    }
+    size_t n = 1;
+    for (auto d : got) n *= (size_t)d;
+    HostTensor& t = c->weights[tf_name];
+    t.shape = got;
+    t.data.assign(data, data + n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = upload(c, t.data, &t.dev);
+    if (rc) return rc;
+    c->packed_ready = false;
+    return DAVO_OK;
+}
+
+int davo_weights_missing(davo_ctx* c) {
+    if (!c) return DAVO_ERR_INVALID;
+    std::string names;
+    const int n = missing_weights(c, &names);
+    if (n) c->err = "weights not loaded: " + names;
+    return n;
+}
+
+int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg,
+                        void* d_pose, float* elapsed_ms) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (!elapsed_ms) return forward_device(c, B, d_img, d_flow, d_seg, d_pose);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    int rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
+    if (rc == DAVO_OK) {
+        HIP_TRY(c, hipEventRecord(e1, c->stream));
+        HIP_TRY(c, hipEventSynchronize(e1));
+        HIP_TRY(c, hipEventElapsedTime(elapsed_ms, e0, e1));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, const float* seg, float* pose_out) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (!img || !flow || !seg || !pose_out) return fail(c, DAVO_ERR_INVALID, "null host pointer");
+    if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t HW = (size_t)c->H * c->W;
+    const size_t nb_img = HW * 9, nb_flow = HW * 8 * sizeof(float), nb_seg = HW * 3 * sizeof(float);
+    if (!c->s_img) {
+        HIP_TRY(c, hipMalloc(&c->s_img, nb_img * c->max_batch));
+        HIP_TRY(c, hipMalloc(&c->s_flow, nb_flow * c->max_batch));
+        HIP_TRY(c, hipMalloc(&c->s_seg, nb_seg * c->max_batch));
+        HIP_TRY(c, hipMalloc(&c->s_pose, (size_t)c->max_batch * 12 * sizeof(float)));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->s_img, img, nb_img * B, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->s_flow, flow, nb_flow * B, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->s_seg, seg, nb_seg * B, hipMemcpyHostToDevice, c->stream));
+    int rc = forward_device(c, B, c->s_img, c->s_flow, c->s_seg, c->s_pose);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(pose_out, c->s_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DAVO_OK;
+}
+
+const char* davo_last_error(const davo_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+void davo_destroy(davo_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->weights) if (kv.second.dev) (void)hipFree(kv.second.dev);
+    for (auto& L : c->L) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_b) (void)hipFree(L.d_b); }
+    for (auto p : c->d_act) if (p) (void)hipFree(p);
+    void* misc[] = {c->d_zeros, c->d_wpred, c->d_bpred, c->d_partial, c->d_tab, c->d_packed, c->s_img, c->s_flow, c->s_seg, c->s_pose};
+    for (auto p : misc) if (p) (void)hipFree(p);
+    for (auto& pe : c->prof_entries)
+        for (auto& ab : pe.pending) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int davo_device_malloc(davo_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMalloc(out, bytes));
+    return DAVO_OK;
+}
+int davo_device_free(davo_ctx* c, void* p) {
+    if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipFree(p));
+    return DAVO_OK;
+}
+int davo_memcpy_h2d(davo_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DAVO_OK;
+}
+int davo_memcpy_d2h(davo_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DAVO_OK;
+}
+int davo_synchronize(davo_ctx* c) {
+    if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DAVO_OK;
+}
+int davo_set_stream(davo_ctx* c, void* hip_stream) {
+    if (!c) return DAVO_ERR_INVALID;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return DAVO_OK;
+}
+
+int davo_profile_enable(davo_ctx* c, int on) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (!on && c->prof) { int rc = prof_collect(c); if (rc) return rc; }
+    c->prof = on != 0;
+    return DAVO_OK;
+}
+int davo_profile_reset(davo_ctx* c) {
+    if (!c) return DAVO_ERR_INVALID;
+    int rc = prof_collect(c);
+    if (rc) return rc;
+    for (auto& pe : c->prof_entries) { pe.launches = 0; pe.total_ms = 0.0; }
+    return DAVO_OK;
+}
+int davo_profile_entry(davo_ctx* c, int i, char* name, int name_len, int* launches, double* total_ms) {
+    if (!c) return DAVO_ERR_INVALID;
+    int rc = prof_collect(c);
+    if (rc) return rc;
+    if (i < 0 || i >= (int)c->prof_entries.size()) return DAVO_ERR_INVALID;
+    const ProfEntry& pe = c->prof_entries[i];
+    if (name && name_len > 0) { strncpy(name, pe.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    if (launches) *launches = pe.launches;
+    if (total_ms) *total_ms = pe.total_ms;
+    return DAVO_OK;
+}
+
+int davo_set_impl(davo_ctx* c, int impl) {
+    if (!c || (impl != 0 && impl != 1)) return fail(c, DAVO_ERR_INVALID, "impl must be 0 (mfma) or 1 (direct)");
+    c->impl = impl;
+    return DAVO_OK;
+}
+
+int davo_debug_read(davo_ctx* c, const char* tensor, float* host_out, size_t n_floats) {
+    if (!c || !tensor || !host_out) return DAVO_ERR_INVALID;
+    if (c->last_B < 1) return fail(c, DAVO_ERR_NOT_READY, "no forward has run yet");
+    const size_t NB = 2 * (size_t)c->last_B;
+    const float* src = nullptr;
+    size_t n = 0;
+    const std::string t = tensor;
+    if (t == "att_table") { src = c->d_tab; n = (size_t)c->last_B * 3 * NCLS; }
+    else if (t == "packed") { src = c->d_packed; n = NB * c->H * c->W * c->packed_ld; }
+    else {
+        const char* names[7] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6", "cnv7"};
+        for (int i = 0; i < 7; ++i)
+            if (t == names[i]) { src = c->d_act[i]; n = NB * c->act_floats_per_img[i]; }
+    }
+    if (!src) return fail(c, DAVO_ERR_INVALID, "unknown tensor `%s'", tensor);
+    if (n != n_floats) return fail(c, DAVO_ERR_INVALID, "`%s' holds %zu floats, caller asked for %zu", tensor, n, n_floats);
+    return davo_memcpy_d2h(c, host_out, src, n * sizeof(float));
+}
+
+int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, const float* w, int k, int Cout,
+                     const float* bias, int stride, int rate, int relu, float* y, char* err, int err_len) {
+    auto bad = [&](const char* m, int code) {
+        if (err && err_len > 0) { strncpy(err, m, err_len - 1); err[err_len - 1] = 0; }
+        return code;
+    };
+    const int cl = ilog2_exact(Cin);
+    if (!x || !w || !bias || !y) return bad("null pointer", DAVO_ERR_INVALID);
+    if (cl < 2) return bad("Cin must be a power of two >= 4", DAVO_ERR_INVALID);
+    if (!(k == 1 || k == 3 || k == 5 || k == 7) || !(stride == 1 || stride == 2) || rate < 1)
+        return bad("k in {1,3,5,7}, stride in {1,2}, rate >= 1", DAVO_ERR_INVALID);
+    if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed", DAVO_ERR_HIP);
+    ConvLayer L;
+    init_layer(L, "conv", k, stride, rate, Cin, Cout, 1);
+    int Ho, Wo, pt, pl;
+    same_pad(H, k, stride, rate, &Ho, &pt);
+    same_pad(W, k, stride, rate, &Wo, &pl);
+    std::vector<float> wp((size_t)L.npad * L.kpad, 0.f), bp(L.npad, 0.f);
+    pack_conv_weights(w, k, Cin, Cout, nullptr, Cin, L.npad, L.kpad, wp.data());
+    memcpy(bp.data(), bias, Cout * sizeof(float));
+    const size_t nx = (size_t)N * H * W * Cin, ny = (size_t)N * Ho * Wo * Cout;
+    float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dz = nullptr;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    chk(hipMalloc(reinterpret_cast<void**>(&dx), nx * 4)); chk(hipMalloc(reinterpret_cast<void**>(&dw), wp.size() * 4));
+    chk(hipMalloc(reinterpret_cast<void**>(&db), bp.size() * 4)); chk(hipMalloc(reinterpret_cast<void**>(&dy), ny * 4));
+    chk(hipMalloc(reinterpret_cast<void**>(&dz), 256));
+    if (e == hipSuccess) {
+        chk(hipMemset(dz, 0, 256));
+        chk(hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice));
+        chk(hipMemcpy(dw, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+        chk(hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+        ConvParams p{};
+        p.x = dx; p.w = dw; p.bias = db; p.y = dy; p.zeros = dz;
+        p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.cin_log2 = cl; p.x_ld = Cin; p.y_ld = Cout;
+        p.Cout = Cout; p.pad_t = pt; p.pad_l = pl; p.rate = rate; p.M = N * Ho * Wo;
+        p.nchunks = L.nchunks; p.Kpad = L.kpad; p.ntaps = k * k; p.ntiles_n = L.npad / L.BN; p.relu = relu;
+        dim3 grid((p.M + BM - 1) / BM * p.ntiles_n, 1);
+        chk(launch_conv(k, stride, L.BN, p, grid, nullptr));
+        chk(hipDeviceSynchronize());
+        chk(hipMemcpy(y, dy, ny * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dz); (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dy);
+    if (e != hipSuccess) return bad(hipGetErrorString(e), DAVO_ERR_HIP);
+    return DAVO_OK;
+}
+
+}  // extern "C"

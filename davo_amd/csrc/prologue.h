@@ -1,0 +1,254 @@
+// prologue.h — the HBM-bound front of the pose path: SE squeeze, the 2->8->19 excitation
+// MLP, and the mask + pack pass that builds the PoseNN input.
+//
+// Reference (all under /root/reference): davo.py:1519-1522 (u8 -> f32 * (1/255) * 2 - 1),
+// data_loader.py:537-557 (strip = src0 | tgt | src1), davo.py:978-982 / 998-1004 (flow planes
+// 0,1; seg file planes src0,tgt,src1), davo.py:1088-1102 (SE input transform),
+// nets/attention_module.py:54-103 (se, mode 'gp'), davo.py:1115,1178 (one_hot . weights ==
+// 19-entry LUT gather, out-of-range id -> 0), nets/posenn.py:380-394 (static weights),
+// davo.py:1404-1442 (masking, concat).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace davo {
+
+constexpr int NCLS = 19;
+constexpr int SQ_CHUNKS = 32;       // partial sums per (triplet, source) plane
+
+struct Variant {
+    int cin_per_frame, cnv6_out, se_act, norm_flow, abs_mode, att_source, mask_rgb, mask_info;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// SE squeeze, pass 1: partial[b][s][chunk][2] = sum over the chunk's pixels of t(flow[b][s]).
+// grid (SQ_CHUNKS, 2, B), 256 threads; float4 = two pixels x (fx, fy).  Fixed chunking and a
+// fixed reduction tree -> bitwise reproducible run to run.
+__global__ __launch_bounds__(256) void se_squeeze_partial(const float* __restrict__ flow, int HW,
+                                                          int norm_flow, int abs_mode,
+                                                          float* __restrict__ partial) {
+    const int chunk = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+    const float4* f = reinterpret_cast<const float4*>(flow + ((size_t)b * 4 + s) * HW * 2);
+    const int nvec = HW / 2;                                   // HW is a multiple of 16
+    const int per = (nvec + SQ_CHUNKS - 1) / SQ_CHUNKS;
+    const int beg = chunk * per, end = min(beg + per, nvec);
+    float sx = 0.f, sy = 0.f;
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        float4 v = f[i];
+        if (norm_flow) {
+            v.x = (v.x - 0.32140523f) / 15.384229f; v.y = (v.y - 0.32140523f) / 15.384229f;
+            v.z = (v.z - 0.32140523f) / 15.384229f; v.w = (v.w - 0.32140523f) / 15.384229f;
+        }
+        if (abs_mode & 1) { v.x = fabsf(v.x); v.z = fabsf(v.z); }
+        if (abs_mode & 2) { v.y = fabsf(v.y); v.w = fabsf(v.w); }
+        sx += v.x + v.z;
+        sy += v.y + v.w;
+    }
+    __shared__ float red[2][4];
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wid] = sx; red[1][wid] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = partial + (((size_t)b * 2 + s) * SQ_CHUNKS + chunk) * 2;
+        o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// SE pass 2 + excitation: tab[b][frame][19] for frame = (tgt, src0, src1).
+// One 64-thread block per triplet; lanes 1,2 run the tiny MLP for src0, src1.
+__global__ __launch_bounds__(64) void se_excite(const float* __restrict__ partial, int HW, Variant v,
+                                                const float* __restrict__ w1, const float* __restrict__ b1,
+                                                const float* __restrict__ w2, const float* __restrict__ b2,
+                                                const float* __restrict__ wstatic,
+                                                float* __restrict__ tab) {
+    const int b = blockIdx.x, frame = threadIdx.x;
+    if (frame >= 3) return;
+    float* t = tab + ((size_t)b * 3 + frame) * NCLS;
+    if (v.att_source == 1 && frame >= 1) {
+        const float* pp = partial + ((size_t)b * 2 + (frame - 1)) * SQ_CHUNKS * 2;
+        float sx = 0.f, sy = 0.f;
+        for (int i = 0; i < SQ_CHUNKS; ++i) { sx += pp[2 * i]; sy += pp[2 * i + 1]; }
+        const float inv = 1.0f / (float)HW;
+        sx *= inv; sy *= inv;                                  // tf.reduce_mean(axis=[1,2])
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = sx * w1[j] + sy * w1[8 + j] + b1[j];     // dense [2,8]
+            e[j] = v.se_act == 1 ? tanhf(z) : v.se_act == 2 ? (z > 0.f ? z : 0.2f * z) : fmaxf(z, 0.f);
+        }
+        for (int c = 0; c < NCLS; ++c) {
+            float z = b2[c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z += e[j] * w2[j * NCLS + c];   // dense [8,19]
+            t[c] = 1.0f / (1.0f + expf(-z));
+        }
+    } else if ((v.att_source == 2 && frame >= 1) || v.att_source == 3) {
+        for (int c = 0; c < NCLS; ++c) t[c] = 1.0f / (1.0f + expf(-wstatic[c]));
+    } else {
+        for (int c = 0; c < NCLS; ++c) t[c] = 1.0f;            // davo.py:1408-1412 / 1385-1389
+    }
+}
+
+__device__ __forceinline__ float att_lookup(const float* tab19, float seg) {
+    const int id = (int)seg;                                   // tf.cast(float -> int32) truncates
+    return (id >= 0 && id < NCLS) ? tab19[id] : 0.f;           // one_hot: out of range -> zero row
+}
+
+__device__ __forceinline__ float u8_to_unit(uint32_t byte) {
+    return (float)byte * (1.0f / 255.0f) * 2.0f - 1.0f;        // davo.py:1521-1522
+}
+
+// Mask + pack: one thread per 4 horizontally adjacent pixels of one pair image.
+// out[(b*2+s)][y][x][0..LD): LD = 8 : tgt rgb | src rgb*att | flow*att      (product layout; the
+//                                      two identically-zero tgt-flow channels are dropped)
+//                            LD = 10: tgt rgb | 0 0 | src rgb*att | flow*att (reference layout)
+// v0 variants (rgb only) leave the flow slots zero.
+template <int LD>
+__global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img, const float* __restrict__ flow,
+                                                 const float* __restrict__ seg, const float* __restrict__ tab,
+                                                 Variant v, int B, int H, int W, float* __restrict__ out) {
+    const int W4 = W >> 2;
+    const long total = (long)B * 2 * H * W4;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int x4 = (int)(gid % W4);
+    long t = gid / W4;
+    const int y = (int)(t % H); t /= H;
+    const int s = (int)(t & 1), b = (int)(t >> 1);
+    const int x = x4 * 4;
+
+    const uint8_t* row = img + ((size_t)b * H + y) * (size_t)(9 * W);
+    const uint32_t* pt = reinterpret_cast<const uint32_t*>(row + (size_t)(W + x) * 3);
+    const uint32_t* ps = reinterpret_cast<const uint32_t*>(row + (size_t)((s ? 2 * W : 0) + x) * 3);
+    const uint32_t t0 = pt[0], t1 = pt[1], t2 = pt[2];
+    const uint32_t s0 = ps[0], s1 = ps[1], s2 = ps[2];
+    const uint8_t tb[12] = {(uint8_t)t0, (uint8_t)(t0 >> 8), (uint8_t)(t0 >> 16), (uint8_t)(t0 >> 24),
+                            (uint8_t)t1, (uint8_t)(t1 >> 8), (uint8_t)(t1 >> 16), (uint8_t)(t1 >> 24),
+                            (uint8_t)t2, (uint8_t)(t2 >> 8), (uint8_t)(t2 >> 16), (uint8_t)(t2 >> 24)};
+    const uint8_t sb[12] = {(uint8_t)s0, (uint8_t)(s0 >> 8), (uint8_t)(s0 >> 16), (uint8_t)(s0 >> 24),
+                            (uint8_t)s1, (uint8_t)(s1 >> 8), (uint8_t)(s1 >> 16), (uint8_t)(s1 >> 24),
+                            (uint8_t)s2, (uint8_t)(s2 >> 8), (uint8_t)(s2 >> 16), (uint8_t)(s2 >> 24)};
+
+    const size_t pix = (size_t)y * W + x;
+    const float4 sg = *reinterpret_cast<const float4*>(seg + ((size_t)b * 3 + (s ? 2 : 0)) * H * W + pix);
+    const float* tab_s = tab + ((size_t)b * 3 + 1 + s) * NCLS;
+    // tf.ones_like overrides are ones everywhere, ignore-label pixels included: every frame for
+    // -no_segmask (davo.py:1387), the tgt frame unless static_all (davo.py:1394,1411).
+    float as[4] = {1.f, 1.f, 1.f, 1.f};
+    if (v.att_source != 0) {
+        as[0] = att_lookup(tab_s, sg.x); as[1] = att_lookup(tab_s, sg.y);
+        as[2] = att_lookup(tab_s, sg.z); as[3] = att_lookup(tab_s, sg.w);
+    }
+    float at[4] = {1.f, 1.f, 1.f, 1.f};
+    if (v.att_source == 3) {                                   // static_all: tgt frame is masked too
+        const float4 tg = *reinterpret_cast<const float4*>(seg + ((size_t)b * 3 + 1) * H * W + pix);
+        const float* tab_t = tab + (size_t)b * 3 * NCLS;
+        at[0] = att_lookup(tab_t, tg.x); at[1] = att_lookup(tab_t, tg.y);
+        at[2] = att_lookup(tab_t, tg.z); at[3] = att_lookup(tab_t, tg.w);
+    }
+    float fl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (v.cin_per_frame == 5) {
+        const float4* fp = reinterpret_cast<const float4*>(flow + (((size_t)b * 4 + s) * H * W + pix) * 2);
+        const float4 f0 = fp[0], f1 = fp[1];
+        fl[0] = f0.x; fl[1] = f0.y; fl[2] = f0.z; fl[3] = f0.w;
+        fl[4] = f1.x; fl[5] = f1.y; fl[6] = f1.z; fl[7] = f1.w;
+    }
+    float* o = out + (((size_t)(b * 2 + s) * H + y) * W + x) * LD;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+        const float mt = v.mask_rgb ? at[px] : 1.f, ms = v.mask_rgb ? as[px] : 1.f;
+        const float mi = v.mask_info ? as[px] : 1.f;
+        float r[10];
+        r[0] = u8_to_unit(tb[3 * px]); r[1] = u8_to_unit(tb[3 * px + 1]); r[2] = u8_to_unit(tb[3 * px + 2]);
+        r[3] = u8_to_unit(sb[3 * px]); r[4] = u8_to_unit(sb[3 * px + 1]); r[5] = u8_to_unit(sb[3 * px + 2]);
+        if (v.mask_rgb) {
+            r[0] *= mt; r[1] *= mt; r[2] *= mt;
+            r[3] *= ms; r[4] *= ms; r[5] *= ms;
+        }
+        r[6] = v.mask_info ? fl[2 * px] * mi : fl[2 * px];
+        r[7] = v.mask_info ? fl[2 * px + 1] * mi : fl[2 * px + 1];
+        if (LD == 8) {
+            *reinterpret_cast<float4*>(o + px * 8) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4*>(o + px * 8 + 4) = make_float4(r[4], r[5], r[6], r[7]);
+        } else {
+            float* q = o + px * 10;
+            q[0] = r[0]; q[1] = r[1]; q[2] = r[2]; q[3] = 0.f; q[4] = 0.f;
+            q[5] = r[3]; q[6] = r[4]; q[7] = r[5]; q[8] = r[6]; q[9] = r[7];
+        }
+    }
+}
+
+// Pose head tail: pred (1x1, 256 -> 3, linear) + mean over H3 x W3 + 0.01 scale
+// (nets/posenn.py:240-241,248-250).  pred and the mean are both linear, so
+//   pose[n][head*3+j] = 0.01 * ( b[j] + (1/P) * sum_c ( sum_p cnv7[n][p][head][c] ) * Wp[c][j] ).
+// grid (2B images, 2 heads), 256 threads = one per cnv7 channel (coalesced rows).
+__global__ __launch_bounds__(256) void pose_head(const float* __restrict__ c7, int P,
+                                                 const float* __restrict__ wpred /*[2][256][3]*/,
+                                                 const float* __restrict__ bpred /*[2][3]*/,
+                                                 float* __restrict__ pose /*[2B][6]*/) {
+    const int n = blockIdx.x, head = blockIdx.y, c = threadIdx.x;
+    const float* src = c7 + (size_t)n * P * 512 + head * 256 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= P; p += 4) {
+        s0 += src[(size_t)p * 512]; s1 += src[(size_t)(p + 1) * 512];
+        s2 += src[(size_t)(p + 2) * 512]; s3 += src[(size_t)(p + 3) * 512];
+    }
+    for (; p < P; ++p) s0 += src[(size_t)p * 512];
+    const float sc = (s0 + s1) + (s2 + s3);
+    const float* wp = wpred + ((size_t)head * 256 + c) * 3;
+    float v[3] = {sc * wp[0], sc * wp[1], sc * wp[2]};
+    __shared__ float red[3][4];
+    const int lane = c & 63, wid = c >> 6;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        v[j] = wave_sum(v[j]);
+        if (lane == 0) red[j][wid] = v[j];
+    }
+    __syncthreads();
+    if (c < 3) {
+        const float tot = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
+        pose[(size_t)n * 6 + head * 3 + c] = 0.01f * (tot / (float)P + bpred[head * 3 + c]);
+    }
+}
+
+// ---- on-device cross-check (impl 1): one thread per output element, reference layouts ----
+__global__ __launch_bounds__(256) void conv_direct(const float* __restrict__ x, int N, int Hin, int Win, int Cin,
+                                                   int x_ld, int x_coff,
+                                                   const float* __restrict__ w /*HWIO*/, int KS, int Cout,
+                                                   const float* __restrict__ bias, int stride, int rate,
+                                                   int pad_t, int pad_l, int Hout, int Wout, int relu,
+                                                   float* __restrict__ y, int y_ld, int y_coff) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)N * Hout * Wout * Cout;
+    if (gid >= total) return;
+    const int co = (int)(gid % Cout);
+    long m = gid / Cout;
+    const int ox = (int)(m % Wout); long t = m / Wout;
+    const int oy = (int)(t % Hout); const int n = (int)(t / Hout);
+    float acc = 0.f;
+    for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * stride - pad_t + ky * rate;
+        if ((unsigned)iy >= (unsigned)Hin) continue;
+        for (int kx = 0; kx < KS; ++kx) {
+            const int ix = ox * stride - pad_l + kx * rate;
+            if ((unsigned)ix >= (unsigned)Win) continue;
+            const float* xp = x + ((size_t)(n * Hin + iy) * Win + ix) * x_ld + x_coff;
+            const float* wp = w + ((size_t)(ky * KS + kx) * Cin) * Cout + co;
+            for (int ci = 0; ci < Cin; ++ci) acc += xp[ci] * wp[(size_t)ci * Cout];
+        }
+    }
+    acc += bias[co];
+    if (relu) acc = fmaxf(acc, 0.f);
+    y[m * y_ld + y_coff + co] = acc;
+}
+
+}  // namespace davo

@@ -1,0 +1,213 @@
+"""Host side of the pose path: the reference's ``DAVO`` call surface over libdavo_hip.so.
+
+Mirrors ``DAVO.__init__`` (reference davo.py:31-33), ``setup_inference`` (davo.py:1533-1551)
+and ``inference`` (davo.py:1553-1569).  The TF reference takes tensors of a tf.data iterator
+and pulls the next batch inside ``sess.run``; here the inputs are numpy arrays, or an iterator
+yielding ``(img_u8, flow, seg)`` batches, pulled once per ``inference`` call.  Weights enter
+through ``load_weights`` — the stand-in for ``tf.train.Saver(...).restore``
+(test_kitti_pose.py:129-131) — keyed by the TF variable names.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .version import parse_version, weight_shapes
+
+
+class DavoError(RuntimeError):
+    pass
+
+
+_PY_ERR = {-1: ValueError, -2: DavoError, -3: DavoError, -4: MemoryError}
+
+
+class DeviceBuffer:
+    """A hipMalloc'd buffer owned through a context (bench / multi-GPU shards keep inputs in HBM)."""
+
+    def __init__(self, engine, nbytes):
+        self.engine, self.nbytes = engine, int(nbytes)
+        p = ctypes.c_void_p()
+        engine._check(_lib.lib().davo_device_malloc(engine._ctx, self.nbytes, ctypes.byref(p)))
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.engine._check(_lib.lib().davo_memcpy_h2d(self.engine._ctx, self.ptr, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.engine._check(_lib.lib().davo_memcpy_d2h(self.engine._ctx, out.ctypes.data_as(ctypes.c_void_p), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.lib().davo_device_free(self.engine._ctx, self.ptr)
+            self.ptr = None
+
+
+class Engine:
+    """Thin object wrapper of one ``davo_ctx`` (one GPU, one host thread)."""
+
+    def __init__(self, cfg, img_height, img_width, max_batch, device=0):
+        self.cfg, self.H, self.W, self.max_batch, self.device = cfg, img_height, img_width, max_batch, device
+        self._L = _lib.lib()
+        self._ctx = ctypes.c_void_p()
+        v = _lib.DavoVariant(*cfg.as_c_ints())
+        rc = self._L.davo_create(ctypes.byref(self._ctx), device, img_height, img_width, max_batch, ctypes.byref(v))
+        if rc != 0:
+            msg = self._L.davo_last_error(self._ctx).decode() if self._ctx else "davo_create failed"
+            if self._ctx:
+                self._L.davo_destroy(self._ctx)
+                self._ctx = ctypes.c_void_p()
+            raise _PY_ERR.get(rc, DavoError)(msg)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _PY_ERR.get(rc, DavoError)(self._L.davo_last_error(self._ctx).decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.davo_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    __del__ = close
+
+    def load_weights(self, weights):
+        want = weight_shapes(self.cfg)
+        for name in want:
+            if name not in weights:
+                raise KeyError("checkpoint has no variable `%s'" % name)
+        for name in want:
+            a = np.ascontiguousarray(weights[name], np.float32)
+            shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+            self._check(self._L.davo_load_weight(self._ctx, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), shape, a.ndim))
+
+    def forward(self, img, flow, seg):
+        img = np.ascontiguousarray(img, np.uint8)
+        flow = np.ascontiguousarray(flow, np.float32)
+        seg = np.ascontiguousarray(seg, np.float32)
+        B = img.shape[0]
+        if img.shape != (B, self.H, 3 * self.W, 3):
+            raise ValueError("img shape %s != %s" % (img.shape, (B, self.H, 3 * self.W, 3)))
+        if flow.shape != (B, 4, self.H, self.W, 2):
+            raise ValueError("flow shape %s != %s" % (flow.shape, (B, 4, self.H, self.W, 2)))
+        if seg.shape != (B, 3, self.H, self.W, 1):
+            raise ValueError("seg shape %s != %s" % (seg.shape, (B, 3, self.H, self.W, 1)))
+        out = np.empty((B, 2, 6), np.float32)
+        vp = ctypes.c_void_p
+        self._check(self._L.davo_forward(self._ctx, B, img.ctypes.data_as(vp), flow.ctypes.data_as(vp),
+                                         seg.ctypes.data_as(vp), out.ctypes.data_as(vp)))
+        return out
+
+    def forward_device(self, B, d_img, d_flow, d_seg, d_pose, timed=False):
+        ms = ctypes.c_float(0.0)
+        self._check(self._L.davo_forward_device(self._ctx, B, d_img.ptr, d_flow.ptr, d_seg.ptr, d_pose.ptr,
+                                                ctypes.byref(ms) if timed else None))
+        return ms.value if timed else None
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def synchronize(self):
+        self._check(self._L.davo_synchronize(self._ctx))
+
+    def set_impl(self, impl):
+        self._check(self._L.davo_set_impl(self._ctx, {"mfma": 0, "direct": 1}.get(impl, impl)))
+
+    def profile(self, on):
+        self._check(self._L.davo_profile_enable(self._ctx, int(on)))
+
+    def profile_reset(self):
+        self._check(self._L.davo_profile_reset(self._ctx))
+
+    def profile_entries(self):
+        out, i = {}, 0
+        name = ctypes.create_string_buffer(64)
+        n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+        while self._L.davo_profile_entry(self._ctx, i, name, 64, ctypes.byref(n), ctypes.byref(ms)) == 0:
+            out[name.value.decode()] = (n.value, ms.value)
+            i += 1
+        return out
+
+    def debug_read(self, tensor, shape):
+        out = np.empty(shape, np.float32)
+        self._check(self._L.davo_debug_read(self._ctx, tensor.encode(), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), out.size))
+        return out
+
+
+def conv2d_same(x, w, b, stride=1, rate=1, relu=True, device=0):
+    """slim.conv2d(padding='SAME') through the MFMA implicit-GEMM kernel (test hook)."""
+    x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    N, H, W, Cin = x.shape
+    k, k2, ci, Cout = w.shape
+    if k != k2 or ci != Cin:
+        raise ValueError("weights %s do not fit input %s" % (w.shape, x.shape))
+    y = np.empty((N, -(-H // stride), -(-W // stride), Cout), np.float32)
+    err = ctypes.create_string_buffer(256)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = _lib.lib().davo_conv2d_same(device, x.ctypes.data_as(fp), N, H, W, Cin, w.ctypes.data_as(fp), k, Cout,
+                                     b.ctypes.data_as(fp), stride, rate, int(relu), y.ctypes.data_as(fp), err, 256)
+    if rc != 0:
+        raise _PY_ERR.get(rc, DavoError)(err.value.decode())
+    return y
+
+
+class DAVO(object):
+    """Drop-in for the reference class on the inference path (reference davo.py:30)."""
+
+    def __init__(self, version=None, att_19=None, device=0):
+        self.version = version          # davo.py:32
+        self.att_19 = att_19            # davo.py:33 (unused on the pose path)
+        self.device = device
+        self.engine = None
+        self._weights = None
+
+    def setup_inference(self, img_height, img_width, mode, seq_length=3, batch_size=1,
+                        input_img_uint8=None, input_pose=None, input_flow=None, input_depth=None,
+                        input_seglabel=None):
+        """davo.py:1533-1551.  ``input_*`` are numpy arrays ([B,H,3W,3] u8, [B,4,H,W,2] f32,
+        [B,3,H,W,1] f32) or ``input_img_uint8`` is an iterator yielding (img, flow, seg);
+        ``input_pose`` / ``input_depth`` are accepted and ignored like the reference does for
+        this variant."""
+        self.img_height, self.img_width, self.mode, self.batch_size = img_height, img_width, mode, batch_size
+        if self.mode != 'davo':
+            return                                        # davo.py:1548: other modes do nothing
+        if seq_length != 3:
+            raise ValueError("seq_length %d: the pose path is built for 3-frame windows" % seq_length)
+        self.seq_length, self.num_source = seq_length, seq_length - 1
+        assert self.version is not None                   # davo.py:959
+        self.cfg = parse_version(self.version)
+        self.engine = Engine(self.cfg, img_height, img_width, batch_size, self.device)
+        if self._weights is not None:
+            self.engine.load_weights(self._weights)
+        if input_img_uint8 is not None and not isinstance(input_img_uint8, np.ndarray) and input_flow is None:
+            self._inputs = iter(input_img_uint8)
+        else:
+            self._inputs = (input_img_uint8, input_flow, input_seglabel)
+
+    def load_weights(self, weights):
+        """Stand-in for tf.train.Saver(tf.trainable_variables()).restore (test_kitti_pose.py:129-131)."""
+        self._weights = weights
+        if self.engine is not None:
+            self.engine.load_weights(weights)
+
+    def inference(self, sess=None, mode='pose', inputs=None):
+        """davo.py:1553-1569: -> {'pose': float32 [B,2,6]}; ``sess`` is accepted and ignored."""
+        if mode != 'pose':
+            raise NotImplementedError("mode `%s': only 'pose' is built (davo.py:1555-1556)" % mode)
+        if self.engine is None:
+            raise DavoError("setup_inference(..., mode='davo') has not been called")
+        if inputs is not None:
+            img, flow, seg = inputs
+        elif isinstance(self._inputs, tuple):
+            img, flow, seg = self._inputs
+        else:
+            img, flow, seg = next(self._inputs)
+        if img is None or flow is None or seg is None:
+            raise ValueError("image, flow and seglabel inputs are all required for version `%s'" % self.version)
+        return {'pose': self.engine.forward(img, flow, seg)}

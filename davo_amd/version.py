@@ -107,7 +107,7 @@ def parse_version(version):
     # -- davo.py:1052-1053
     m = re.search("-cnv6_([0-9]+)", v)
     cnv6_out = 128 if m is None else int(m.group(1))
-    if cnv6_out % 32 != 0 or not (32 <= cnv6_out <= 256):
+    if cnv6_out not in (32, 64, 128, 256):          # the cnv7 k-order needs a power-of-two Cin
         raise UnsupportedVariantError("version `%s': cnv6 width %d is not supported." % (v, cnv6_out))
 
     # -- davo.py:1056-1065

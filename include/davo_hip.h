@@ -1,0 +1,124 @@
+/* davo_hip.h — C ABI of libdavo_hip.so: DAVO frame-to-frame pose inference on MI355X (gfx950).
+ *
+ * The reference (BassyKuo/DAVO, TensorFlow 1.13) has no plugin/FFI layer: this path sits
+ * behind the Python class DAVO (reference davo.py:30).  Each entry point below names the
+ * reference interface it stands in for; davo_amd/davo.py is the ctypes host side that keeps
+ * the reference's call surface on top of it.  Plain pointers and sizes only — no torch, no
+ * TF types.  A context is NOT thread-safe: one context per GPU per host thread (the reference
+ * drives sess.run from a single thread, test_kitti_pose.py:133-145).
+ *
+ * Every function returns 0 on success and a negative davo_status on failure; the message is
+ * available from davo_last_error().  Tensor layouts are the reference's: NHWC, float32 unless
+ * stated, HWIO convolution kernels, [in,out] dense kernels.
+ */
+#ifndef DAVO_HIP_H
+#define DAVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct davo_ctx davo_ctx;
+
+typedef enum {
+    DAVO_OK = 0,
+    DAVO_ERR_INVALID = -1,      /* bad argument / shape / unsupported variant */
+    DAVO_ERR_HIP = -2,          /* a HIP runtime call failed                   */
+    DAVO_ERR_NOT_READY = -3,    /* forward before every weight was loaded      */
+    DAVO_ERR_NOMEM = -4
+} davo_status;
+
+/* What the reference derives from the --version string (davo.py:1010-1102,1117-1450);
+ * davo_amd/version.py:parse_version() fills it.  Field order is ABI. */
+typedef struct {
+    int32_t cin_per_frame;  /* 5: rgb+flow ("v1", davo.py:1062-1065) | 3: rgb only ("v0")        */
+    int32_t cnv6_out;       /* -cnv6_(\d+), default 128 (davo.py:1052-1053); multiple of 32       */
+    int32_t se_act;         /* 0 relu | 1 tanh | 2 leaky_relu(0.2)   (davo.py:1077-1085)          */
+    int32_t norm_flow;      /* (f-0.32140523)/15.384229 on the SE input (davo.py:1089-1091)       */
+    int32_t abs_mode;       /* 0 none | 1 |f_x| | 2 |f_y| | 3 |f|      (davo.py:1094-1102)        */
+    int32_t att_source;     /* 0 ones (-no_segmask) | 1 se_flow | 2 static, tgt=1 | 3 static, all */
+    int32_t mask_rgb;       /* rgb_k *= att_k                          (davo.py:1419-1423)        */
+    int32_t mask_info;      /* flow_k *= att_k  (-segmask_all)         (davo.py:1430-1434)        */
+} davo_variant;
+
+/* Replaces DAVO(version).setup_inference(img_height, img_width, 'davo', 3, batch_size, ...)
+ * (davo.py:1533-1551 -> build_pose_test_graph_davo, davo.py:955-1494): creates the device
+ * context (workspace for up to max_batch triplets of H x W frames) on HIP device `device`.
+ * H and W must be multiples of 4. */
+int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const davo_variant* v);
+
+/* Replaces tf.train.Saver(tf.trainable_variables()).restore(sess, ckpt)
+ * (test_kitti_pose.py:129-131), one tensor at a time, keyed by the TF variable name
+ * (e.g. "pose_exp_net/cnv1/weights", "pose_exp_net/pose/rotation/cnv6/biases",
+ * "pose_exp_net/se_flow/bottleneck_fc/kernel").  `data` is a host pointer; the context keeps
+ * its own (re-laid-out) device copy. */
+int davo_load_weight(davo_ctx* ctx, const char* tf_name, const float* data,
+                     const int64_t* shape, int ndim);
+
+/* Number of weight tensors the variant still needs (0 = ready); names of the missing ones are
+ * left in davo_last_error(). */
+int davo_weights_missing(davo_ctx* ctx);
+
+/* Replaces DAVO.inference(sess, mode='pose') (davo.py:1553-1569 -> sess.run({'pose': pred_poses})).
+ * Host pointers, shapes as the reference's test driver sets them (test_kitti_pose.py:110-114):
+ *   img  uint8 [B,H,3W,3]  (strip src0|tgt|src1, data_loader.py:537-557)
+ *   flow f32   [B,4,H,W,2] (planes 0,1 used, davo.py:978-982)
+ *   seg  f32   [B,3,H,W,1] (file order src0,tgt,src1, davo.py:998-1004)
+ *   pose_out f32 [B,2,6]   rows = (tgt->src0, tgt->src1), each [rz,ry,rx,tx,ty,tz]
+ * Synchronous: returns after pose_out is written.  1 <= B <= max_batch. */
+int davo_forward(davo_ctx* ctx, int B, const uint8_t* img, const float* flow, const float* seg,
+                 float* pose_out);
+
+/* Same computation on device-resident buffers (the path bench.py times; multi-GPU shards keep
+ * their windows in HBM).  Asynchronous on the context's stream unless elapsed_ms != NULL, in
+ * which case it is bracketed by HIP events, synchronised, and the device time is returned. */
+int davo_forward_device(davo_ctx* ctx, int B, const void* d_img, const void* d_flow,
+                        const void* d_seg, void* d_pose, float* elapsed_ms);
+
+const char* davo_last_error(const davo_ctx* ctx);
+void davo_destroy(davo_ctx* ctx);
+
+/* ---- device memory / stream plumbing for hosts without a HIP binding (ctypes) ---------- */
+int davo_device_malloc(davo_ctx* ctx, size_t bytes, void** out);
+int davo_device_free(davo_ctx* ctx, void* p);
+int davo_memcpy_h2d(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
+int davo_memcpy_d2h(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
+int davo_synchronize(davo_ctx* ctx);
+/* Run on a caller-owned hipStream_t (NULL restores the context's own stream). */
+int davo_set_stream(davo_ctx* ctx, void* hip_stream);
+
+/* ---- measurement ---------------------------------------------------------
+ * With profiling on, every kernel launch of davo_forward[_device] is bracketed by HIP events
+ * on the launch stream.  davo_profile_entry(i) returns the kernel's label, number of timed
+ * launches and total device milliseconds since the last davo_profile_reset(); it returns
+ * DAVO_ERR_INVALID once i is past the last entry.  Reading synchronises the stream. */
+int davo_profile_enable(davo_ctx* ctx, int on);
+int davo_profile_reset(davo_ctx* ctx);
+int davo_profile_entry(davo_ctx* ctx, int i, char* name, int name_len, int* launches,
+                       double* total_ms);
+
+/* ---- test hooks -------------------------------------------------------------------------
+ * impl 0 = MFMA implicit-GEMM kernels (default, the product path);
+ * impl 1 = one-thread-per-output direct convolution in HIP on the reference's own tensor
+ *          layouts (10-channel input, HWIO weights) — an on-device cross-check, never timed. */
+int davo_set_impl(davo_ctx* ctx, int impl);
+
+/* Copy an intermediate of the LAST forward to host (float32, NHWC, pair-image major = 2B images):
+ * "att_table" [B,3,19], "packed" [2B,H,W,8|10], "cnv1".."cnv5", "cnv6" [.., 2*cnv6_out]
+ * (rotation | translation), "cnv7" [.., 512].  n_floats must equal the tensor size. */
+int davo_debug_read(davo_ctx* ctx, const char* tensor, float* host_out, size_t n_floats);
+
+/* Stand-alone slim.conv2d(padding='SAME') (nets/posenn.py:205-215) through the same MFMA
+ * kernel, host pointers: x [N,H,W,Cin] (Cin a power of two >= 4), w HWIO [k,k,Cin,Cout],
+ * y [N,ceil(H/stride),ceil(W/stride),Cout].  k in {1,3,5,7}, stride in {1,2}. */
+int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin,
+                     const float* w, int k, int Cout, const float* bias,
+                     int stride, int rate, int relu, float* y, char* err, int err_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAVO_HIP_H */

@@ -168,10 +168,14 @@ void oracle_pack(const oracle_variant* v, int B, int H, int W, const uint8_t* im
                     const uint8_t* row = img + ((size_t)b * H + y) * 3 * W * 3;
                     const uint8_t* pt = row + (size_t)(W + x) * 3;
                     const uint8_t* ps = row + (size_t)((s ? 2 * W : 0) + x) * 3;
-                    const float at = att_at(tab + ((size_t)b * 3 + 0) * NCLS,
-                                            seg[(((size_t)b * 3 + 1) * H + y) * W + x]);
-                    const float as = att_at(tab + ((size_t)b * 3 + 1 + s) * NCLS,
-                                            seg[(((size_t)b * 3 + (s ? 2 : 0)) * H + y) * W + x]);
+                    /* tf.ones_like overrides are ones everywhere, ignore pixels included:
+                     * tgt unless static_all (davo.py:1394,1411); every frame for -no_segmask (:1387) */
+                    const float at = v->att_source == 3
+                        ? att_at(tab + ((size_t)b * 3 + 0) * NCLS, seg[(((size_t)b * 3 + 1) * H + y) * W + x])
+                        : 1.f;
+                    const float as = v->att_source == 0 ? 1.f
+                        : att_at(tab + ((size_t)b * 3 + 1 + s) * NCLS,
+                                 seg[(((size_t)b * 3 + (s ? 2 : 0)) * H + y) * W + x]);
                     for (int k = 0; k < C; ++k) o[k] = 0.f;
                     for (int k = 0; k < 3; ++k) {
                         float t = (float)pt[k] * inv255 * 2.0f - 1.0f;

@@ -132,8 +132,15 @@ def pack_inputs(cfg, img_u8, flow, seg, weights, dtype=np.float64):
     x = preprocess_image(img_u8, dtype)
     src0, tgt, src1 = x[:, :, :W], x[:, :, W:2 * W], x[:, :, 2 * W:]       # data_loader.py:537-557
     tab = attention_tables(cfg, flow, weights, dtype)
-    att_tgt = attention_map(tab[:, 0], seg[:, 1])                          # seg file order (src0,tgt,src1)
-    att = [attention_map(tab[:, 1], seg[:, 0]), attention_map(tab[:, 2], seg[:, 2])]
+    ones = np.ones((B, H, W, 1), dtype)
+    # seg file order is (src0,tgt,src1).  tf.ones_like(map) overrides are ones EVERYWHERE,
+    # ignore-label pixels included: tgt for se_flow (davo.py:1411) and static_src (:1394),
+    # all three frames for -no_segmask (:1387).
+    att_tgt = attention_map(tab[:, 0], seg[:, 1]) if cfg.att_source == "static_all" else ones
+    if cfg.att_source == "ones":
+        att = [ones, ones]
+    else:
+        att = [attention_map(tab[:, 1], seg[:, 0]), attention_map(tab[:, 2], seg[:, 2])]
     out = np.zeros((B, 2, H, W, 2 * cfg.cin_per_frame), dtype)
     c = cfg.cin_per_frame
     for s, src in enumerate((src0, src1)):

@@ -1,0 +1,56 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/davo_hip.h
+declares; no compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from davo_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    return _lib.build()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "davo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(davo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_matches_binding():
+    assert set(declared_symbols()) == set(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(built):
+    L = ctypes.CDLL(built)
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+
+
+def test_variant_struct_layout():
+    assert ctypes.sizeof(_lib.DavoVariant) == 32            # 8 x int32, field order is ABI
+
+
+def test_no_gpu_fails_loudly(built):
+    """Without a GPU the product path raises; it never falls back to a CPU implementation."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from davo_amd import DAVO, FLAGSHIP_VERSION, DavoError
+    d = DAVO(FLAGSHIP_VERSION)
+    with pytest.raises((DavoError, ValueError)):
+        d.setup_inference(128, 416, 'davo', 3, 1)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "davo_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("# oracle", ""), os.path.join(dirpath, f)

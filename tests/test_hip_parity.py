@@ -1,0 +1,200 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the CPU oracle and the committed
+golden outputs.  Bar: max|pose - ref| <= 1e-4 AND <= 1e-4*max|ref|.
+The oracle is the checker only; nothing here falls back to it."""
+import numpy as np
+import pytest
+
+from davo_amd import DAVO, Engine, conv2d_same, synth, parse_version, FLAGSHIP_VERSION, DavoError
+from oracle import davo_oracle as O
+
+from helpers import load_golden, case_inputs, assert_pose_close, assert_layer_close
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- the MFMA implicit-GEMM kernel alone ---------------------------------------------------
+@pytest.mark.parametrize("k,stride,rate,cin,cout,N,H,W", [
+    (7, 2, 1, 8, 16, 2, 32, 48),        # cnv1 shape class: Cin < 32 (4 taps per k-chunk), N tile half empty
+    (5, 2, 1, 16, 32, 2, 33, 47),       # cnv2 class, odd sizes -> asymmetric SAME pad
+    (3, 1, 2, 32, 64, 3, 32, 104),      # cnv3
+    (3, 1, 4, 64, 128, 1, 32, 104),     # cnv4
+    (3, 1, 8, 128, 256, 1, 32, 104),    # cnv5: rate 8, two N tiles
+    (3, 1, 2, 256, 256, 1, 16, 40),     # cnv6 fused width
+    (3, 2, 1, 128, 256, 2, 32, 104),    # cnv7: stride 2, pad (0,1)
+    (1, 1, 1, 256, 3, 1, 16, 52),       # pred: 1x1, N = 3
+    (3, 1, 1, 4, 5, 1, 9, 11),          # ragged everything: M tail, K tail, N tail
+    (3, 2, 3, 16, 40, 2, 21, 19),
+])
+def test_conv_kernel_vs_oracle(k, stride, rate, cin, cout, N, H, W):
+    rng = np.random.RandomState(1000 * k + 100 * stride + 10 * rate + cin)
+    x = rng.randn(N, H, W, cin).astype(np.float32)
+    w = (rng.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    b = (rng.randn(cout) * 0.1).astype(np.float32)
+    for relu in (True, False):
+        want = O.conv2d_same(x.astype(np.float64), w, b, stride, rate, relu)
+        got = conv2d_same(x, w, b, stride, rate, relu)
+        assert_layer_close(got, want, "conv k%d s%d r%d %d->%d relu=%s" % (k, stride, rate, cin, cout, relu), rtol=5e-6)
+
+
+def test_conv_kernel_asymmetric_operand():
+    """A = identity-like input with an asymmetric kernel catches a transposed C/D map."""
+    x = np.zeros((1, 8, 8, 32), np.float32)
+    x[0, 3, 5, :] = np.arange(1, 33)
+    w = np.zeros((1, 1, 32, 64), np.float32)
+    for ci in range(32):
+        w[0, 0, ci, (3 * ci + 1) % 64] = 1.0 + ci
+    got = conv2d_same(x, w, np.zeros(64, np.float32), 1, 1, False)
+    want = O.conv2d_same(x.astype(np.float64), w, np.zeros(64), 1, 1, False)
+    assert np.array_equal(got, want.astype(np.float32))
+
+
+# ---- whole path, layer by layer ------------------------------------------------------------
+def _engine(cfg, H, W, B, weights):
+    e = Engine(cfg, H, W, B)
+    e.load_weights(weights)
+    return e
+
+
+def _repack10_to_8(p10):
+    return np.concatenate([p10[..., 0:3], p10[..., 5:10]], axis=-1)
+
+
+@pytest.mark.parametrize("impl", ["mfma", "direct"])
+def test_layers_flagship_128x416(impl):
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B, H, W = 1, 128, 416
+    img, flow, seg = synth.make_inputs(B, H, W)
+    weights = synth.make_weights(cfg)
+    keep = {}
+    want = O.forward(cfg, img, flow, seg, weights, np.float64, keep)
+    e = _engine(cfg, H, W, B, weights)
+    e.set_impl(impl)
+    got = e.forward(img, flow, seg)
+    tab = e.debug_read("att_table", (B, 3, 19))
+    assert_layer_close(tab[:, 1:], O.attention_tables(cfg, flow, weights, np.float64)[:, 1:], "att_table", rtol=2e-6)
+    p10 = keep["packed"].reshape(2 * B, H, W, 10)
+    if impl == "mfma":
+        assert_layer_close(e.debug_read("packed", (2 * B, H, W, 8)), _repack10_to_8(p10), "packed", rtol=2e-6)
+    else:
+        assert_layer_close(e.debug_read("packed", (2 * B, H, W, 10)), p10, "packed10", rtol=2e-6)
+    for name, shp in (("cnv1", (64, 208, 16)), ("cnv2", (32, 104, 32)), ("cnv3", (32, 104, 64)),
+                      ("cnv4", (32, 104, 128)), ("cnv5", (32, 104, 256))):
+        assert_layer_close(e.debug_read(name, (2 * B,) + shp), keep[name], name)
+    c6 = e.debug_read("cnv6", (2 * B, 32, 104, 256))
+    assert_layer_close(c6[..., :128], keep["rotation/cnv6"], "rot cnv6")
+    assert_layer_close(c6[..., 128:], keep["translation/cnv6"], "trans cnv6")
+    c7 = e.debug_read("cnv7", (2 * B, 16, 52, 512))
+    assert_layer_close(c7[..., :256], keep["rotation/cnv7"], "rot cnv7")
+    assert_layer_close(c7[..., 256:], keep["translation/cnv7"], "trans cnv7")
+    assert_pose_close(got, want, "pose (%s)" % impl)
+    e.close()
+
+
+def test_golden_cases_all_variants(c_oracle):
+    g = load_golden()
+    for name, case in g["cases"].items():
+        cfg, img, flow, seg, weights = case_inputs(case)
+        e = _engine(cfg, case["H"], case["W"], case["B"], weights)
+        got = e.forward(img, flow, seg)
+        assert_pose_close(got, np.array(case["pose"]), name + " vs golden")
+        if case["H"] * case["W"] <= 128 * 416:
+            assert_pose_close(got, c_oracle.forward(cfg, img, flow, seg, weights), name + " vs C oracle")
+        e.close()
+
+
+def test_batching_is_per_sample_and_deterministic():
+    """A window's pose must not depend on what else is in the batch or on max_batch."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(5, 128, 416)
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, 128, 416, 8, weights)
+    all5 = e.forward(img, flow, seg)
+    again = e.forward(img, flow, seg)
+    assert np.array_equal(all5, again)                       # bitwise reproducible
+    for i in (0, 3, 4):
+        one = e.forward(img[i:i + 1], flow[i:i + 1], seg[i:i + 1])
+        assert np.array_equal(one[0], all5[i])
+    rev = e.forward(img[::-1], flow[::-1], seg[::-1])
+    assert np.array_equal(rev[::-1], all5)
+    e.close()
+
+
+def test_linearity_of_pose_head():
+    """pred + mean are linear: scaling the pred kernel and bias by a scales the pose by a."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(1, 64, 96)
+    w = synth.make_weights(cfg)
+    e = _engine(cfg, 64, 96, 1, w)
+    p1 = e.forward(img, flow, seg)
+    w2 = dict(w)
+    for h in ("rotation", "translation"):
+        for k in ("weights", "biases"):
+            n = "pose_exp_net/pose/%s/pred/%s" % (h, k)
+            w2[n] = w[n] * np.float32(0.5)
+    e.load_weights(w2)
+    p2 = e.forward(img, flow, seg)
+    assert np.allclose(p2, 0.5 * p1, rtol=2e-6, atol=1e-9)
+    e.close()
+
+
+def test_ignore_label_everywhere_zeroes_sources():
+    """seg = 255 everywhere -> src rgb and flow are fully masked: the pose equals the pose of a
+    window whose source frames are black(-ish: value 0 after masking) with zero flow."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(1, 64, 96)
+    w = synth.make_weights(cfg)
+    seg255 = np.full_like(seg, 255.0)
+    want = O.forward(cfg, img, flow, seg255, w)
+    e = _engine(cfg, 64, 96, 1, w)
+    got = e.forward(img, flow, seg255)
+    assert_pose_close(got, want, "all-ignore")
+    flow2 = flow.copy(); flow2[:, :2] *= 3.0               # masked out -> no effect at all
+    assert np.array_equal(e.forward(img, flow2, seg255), got)
+    e.close()
+
+
+# ---- the reference call surface ------------------------------------------------------------
+def test_davo_class_call_surface():
+    g = load_golden()["cases"]["flagship_b2_128x416"]
+    cfg, img, flow, seg, weights = case_inputs(g)
+    system = DAVO(version=FLAGSHIP_VERSION)
+    system.setup_inference(128, 416, "davo", 3, 2, img, input_flow=flow, input_depth=seg, input_seglabel=seg)
+    system.load_weights(weights)
+    pred = system.inference(None, mode='pose')
+    assert set(pred) == {'pose'} and pred['pose'].shape == (2, 2, 6) and pred['pose'].dtype == np.float32
+    assert_pose_close(pred['pose'], np.array(g["pose"]), "DAVO.inference")
+    with pytest.raises(NotImplementedError):
+        system.inference(None, mode='feature')
+
+    # pull-model: an iterator of batches stands in for the tf.data get_next()
+    def batches():
+        for i in range(2):
+            yield img[i:i + 1], flow[i:i + 1], seg[i:i + 1]
+    s2 = DAVO(version=FLAGSHIP_VERSION)
+    s2.load_weights(weights)
+    s2.setup_inference(128, 416, "davo", 3, 1, batches())
+    for i in range(2):
+        assert_pose_close(s2.inference(None, 'pose')['pose'][0], np.array(g["pose"])[i], "window %d" % i)
+
+
+def test_error_behaviour():
+    cfg = parse_version(FLAGSHIP_VERSION)
+    weights = synth.make_weights(cfg)
+    img, flow, seg = synth.make_inputs(2, 64, 96)
+    e = Engine(cfg, 64, 96, 1)
+    with pytest.raises(DavoError, match="weights not loaded"):
+        e.forward(img[:1], flow[:1], seg[:1])
+    bad = dict(weights)
+    bad["pose_exp_net/cnv1/weights"] = np.zeros((7, 7, 6, 16), np.float32)
+    with pytest.raises(ValueError, match="does not match expected"):
+        e.load_weights(bad)
+    e.load_weights(weights)
+    with pytest.raises(ValueError, match="batch 2 outside"):
+        e.forward(img, flow, seg)
+    with pytest.raises(ValueError):
+        e.forward(img[:1], flow[:1, :2], seg[:1])
+    e.close()
+    with pytest.raises(ValueError, match="multiples of 4"):
+        Engine(cfg, 62, 96, 1)
+    with pytest.raises(NameError):
+        DAVO("v1-sharedNN-dilatedPoseNN-se_spp_flow").setup_inference(64, 96, "davo")
