@@ -29,6 +29,18 @@ PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: FP32
 PEAK_HBM_GBS = 8000.0
 
 
+def usable_cores():
+    """host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,7 +157,7 @@ def main():
                                    "triplets, dilatedPoseNN-cnv6_128 + se_flow + fc_tanh" % (B, H, W),
                        "version": FLAGSHIP_VERSION, "batch_per_gpu": B, "height": H, "width": W,
                        "parallelism": "window-sharded replicas x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32<3,1,128> (cnv6, rotation|translation fused)",
+            "roofline": {"bound": "mfma", "kernel": "davo::conv_igemm_f32<3,1,128,6> (cnv6: rotation|translation fused, N=256, K=2304)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                          "avg_launch_ms": round(avg6, 4), "flops_per_launch": cnv6_flops_per_launch},
@@ -163,12 +175,12 @@ def main():
         res["oracle_note"] = "CPU restatement (TF1 itself cannot run offline: parity unpinned vs TF)"
         if world == 1 and not args.no_cpu_baseline:
             nb = max(1, min(args.cpu_sample, B))
-            cores = c_oracle.max_threads()
-            c_oracle.forward(cfg, img[:1], flow[:1], seg[:1], weights)         # warm-up
+            cores = usable_cores()
+            c_oracle.forward(cfg, img[:1], flow[:1], seg[:1], weights, nthreads=cores)   # warm-up
             c0 = time.perf_counter()
             passes = 0
             while passes < 3 or time.perf_counter() - c0 < 10.0:
-                c_oracle.forward(cfg, img[:nb], flow[:nb], seg[:nb], weights)
+                c_oracle.forward(cfg, img[:nb], flow[:nb], seg[:nb], weights, nthreads=cores)
                 passes += 1
                 if time.perf_counter() - c0 > 30.0:
                     break

@@ -70,7 +70,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return start + (bid >> 3);
 }
 
-template <int KS, int STRIDE, int BN>
+// LAYER only names the instantiation (0 = generic, 1..7 = cnv1..cnv7) so that rocprofv3's
+// per-kernel statistics separate the layers that share a tile shape (cnv4/cnv5/cnv6).
+template <int KS, int STRIDE, int BN, int LAYER>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     using T = Tile<BN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];

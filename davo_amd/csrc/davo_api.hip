@@ -113,10 +113,10 @@ int fail(davo_ctx* c, int code, const char* fmt, ...) {
     } while (0)
 
 // ---- conv dispatch ----------------------------------------------------------------------
-template <int KS, int STRIDE, int BN>
+template <int KS, int STRIDE, int BN, int LAYER>
 hipError_t launch_conv_t(const ConvParams& p, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_igemm_f32<KS, STRIDE, BN>;
+    auto kern = conv_igemm_f32<KS, STRIDE, BN, LAYER>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Tile<BN>::LDS_BYTES);
@@ -130,13 +130,14 @@ hipError_t launch_conv_t(const ConvParams& p, dim3 grid, hipStream_t s) {
 template <int KS, int STRIDE>
 hipError_t launch_conv_bn(int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
     switch (BN) {
-        case 32: return launch_conv_t<KS, STRIDE, 32>(p, grid, s);
-        case 64: return launch_conv_t<KS, STRIDE, 64>(p, grid, s);
-        case 128: return launch_conv_t<KS, STRIDE, 128>(p, grid, s);
+        case 32: return launch_conv_t<KS, STRIDE, 32, 0>(p, grid, s);
+        case 64: return launch_conv_t<KS, STRIDE, 64, 0>(p, grid, s);
+        case 128: return launch_conv_t<KS, STRIDE, 128, 0>(p, grid, s);
     }
     return hipErrorInvalidValue;
 }
 
+// generic shapes (davo_conv2d_same and non-default cnv6 widths)
 hipError_t launch_conv(int KS, int stride, int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
     if (stride == 1) {
         switch (KS) {
@@ -152,6 +153,20 @@ hipError_t launch_conv(int KS, int stride, int BN, const ConvParams& p, dim3 gri
             case 5: return launch_conv_bn<5, 2>(BN, p, grid, s);
             case 7: return launch_conv_bn<7, 2>(BN, p, grid, s);
         }
+    }
+    return hipErrorInvalidValue;
+}
+
+// the seven PoseNN launches, each under its own kernel name (LAYER tag)
+hipError_t launch_layer(int layer, int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
+    switch (layer) {
+        case 0: return launch_conv_t<7, 2, 32, 1>(p, grid, s);
+        case 1: return launch_conv_t<5, 2, 32, 2>(p, grid, s);
+        case 2: return launch_conv_t<3, 1, 64, 3>(p, grid, s);
+        case 3: return launch_conv_t<3, 1, 128, 4>(p, grid, s);
+        case 4: return launch_conv_t<3, 1, 128, 5>(p, grid, s);
+        case 5: return BN == 128 ? launch_conv_t<3, 1, 128, 6>(p, grid, s) : launch_conv_t<3, 1, 64, 6>(p, grid, s);
+        case 6: return launch_conv_t<3, 2, 128, 7>(p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -387,7 +402,7 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
     const int mtiles = (p.M + BM - 1) / BM;
     dim3 grid(mtiles * p.ntiles_n, L.groups);
     ProfScope ps(c, L.label);
-    HIP_TRY(c, launch_conv(L.KS, L.stride, L.BN, p, grid, c->stream));
+    HIP_TRY(c, launch_layer(li, L.BN, p, grid, c->stream));
     return DAVO_OK;
 }
 
