@@ -1,0 +1,83 @@
+"""Sequence inference driver — the counterpart of the reference's ``test_kitti_pose.py``
+(flags ``:20-29``, main ``:75-154``): runs the pose path over a KITTI odometry sequence and
+writes ``<seq>-pred_kitti_pose.txt``.
+
+    python -m davo_amd.run_kitti_pose --test_seq 3 --concat_img_dir DUMP --ckpt_file W.npz \
+        --output_dir out --version v1-...                    # one GPU
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
+        -m davo_amd.run_kitti_pose ... --batch_size 64       # windows sharded over 8 GPUs
+
+``--ckpt_file`` is an ``.npz`` keyed by the TF variable names (SURVEY table W); with
+``--synthetic N`` the inputs and weights are the seeded synthetic ones (no KITTI dump or
+checkpoint exists offline) and N is the frame count (801 = seq 03, 4541 = seq 00).
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+
+from . import sequence as S
+from .davo import DAVO
+from .version import FLAGSHIP_VERSION
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch_size", type=int, default=1)          # test_kitti_pose.py:21
+    ap.add_argument("--img_height", type=int, default=128)
+    ap.add_argument("--img_width", type=int, default=416)
+    ap.add_argument("--seq_length", type=int, default=3)
+    ap.add_argument("--test_seq", type=int, default=9)
+    ap.add_argument("--concat_img_dir", default=None)
+    ap.add_argument("--output_dir", required=True)
+    ap.add_argument("--ckpt_file", default=None)
+    ap.add_argument("--version", default=FLAGSHIP_VERSION)
+    ap.add_argument("--synthetic", type=int, default=0, help="frame count of a synthetic sequence")
+    a = ap.parse_args(argv)
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    H, W = a.img_height, a.img_width
+    if a.synthetic:
+        from . import synth
+        n_frames = a.synthetic
+        load = S.synthetic_window_loader(H, W)
+        weights = synth.make_weights(a.version)
+    else:
+        from glob import glob
+        d = os.path.join(a.concat_img_dir, "%.2d" % a.test_seq)
+        n_frames = len(glob(d + "/*.jpg")) + 2 * int((a.seq_length - 1) / 2)      # test_kitti_pose.py:81-82
+        load = S.kitti_window_loader(a.concat_img_dir, a.test_seq, n_frames, H, W)
+        weights = dict(np.load(a.ckpt_file))
+
+    system = DAVO(version=a.version, device=local_rank)
+    system.load_weights(weights)
+    system.setup_inference(H, W, "davo", a.seq_length, a.batch_size)
+    infer = lambda img, flow, seg: system.inference(None, "pose", inputs=(img, flow, seg))["pose"]   # noqa: E731
+
+    t0 = time.perf_counter()
+    traj, poses = S.run_sequence(infer, load, n_frames, a.batch_size, rank, world, device)
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        os.makedirs(a.output_dir, exist_ok=True)
+        out = os.path.join(a.output_dir, "%.2d-pred_kitti_pose.txt" % a.test_seq)   # :116
+        S.write_kitti_poses(out, traj)
+        print("Done. Please check %s  (%d windows on %d GPU(s) in %.2f s incl. input generation/IO)"
+              % (out, n_frames - 2, world, dt))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

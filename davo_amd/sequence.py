@@ -1,0 +1,192 @@
+"""Sequence driver around the pose path: window sharding across GPUs, the one pose gather,
+and the trajectory stitch + KITTI writer that follow the path in the reference's test driver.
+
+Reference: ``test_kitti_pose.py:75-154`` (driver; hot loop ``:133-145``, chain ``:147-149``,
+writer ``:150-153``), ``utils/geo_utils.py:12-63,93-119`` (``euler2mat`` clips to [-pi,pi],
+R = Rx.Ry.Rz; ``pose_vec2mat`` on ``[rz,ry,rx,tx,ty,tz]``), ``utils/common_utils.py:8-28``.
+
+The windows of a sequence are independent (each ``[2,6]`` output depends only on its own
+3 frames), so ranks take contiguous window ranges and run them with no data-path collective;
+the only exchange is one gather of ``[n,2,6]`` float32 before the sequential 4x4 chain
+(48 B per window: 218 KB for KITTI seq 00 — latency only, on RCCL over xGMI).
+"""
+import os
+
+import numpy as np
+
+
+# ---- geometry (utils/geo_utils.py) --------------------------------------------------------
+def euler2mat(z, y, x, dtype=np.float32):
+    """R = Rx(x).Ry(y).Rz(z) with angles clipped to [-pi,pi] (geo_utils.py:12-63).
+    The reference evaluates this in a float32 TF graph (test_kitti_pose.py:122-123)."""
+    z = np.clip(np.asarray(z, dtype), -np.pi, np.pi)
+    y = np.clip(np.asarray(y, dtype), -np.pi, np.pi)
+    x = np.clip(np.asarray(x, dtype), -np.pi, np.pi)
+    n = z.shape[0]
+    cz, sz, cy, sy, cx, sx = np.cos(z), np.sin(z), np.cos(y), np.sin(y), np.cos(x), np.sin(x)
+    zmat = np.zeros((n, 3, 3), dtype); ymat = np.zeros((n, 3, 3), dtype); xmat = np.zeros((n, 3, 3), dtype)
+    zmat[:, 0, 0] = cz; zmat[:, 0, 1] = -sz; zmat[:, 1, 0] = sz; zmat[:, 1, 1] = cz; zmat[:, 2, 2] = 1
+    ymat[:, 0, 0] = cy; ymat[:, 0, 2] = sy; ymat[:, 1, 1] = 1; ymat[:, 2, 0] = -sy; ymat[:, 2, 2] = cy
+    xmat[:, 0, 0] = 1; xmat[:, 1, 1] = cx; xmat[:, 1, 2] = -sx; xmat[:, 2, 1] = sx; xmat[:, 2, 2] = cx
+    return np.matmul(np.matmul(xmat, ymat), zmat)
+
+
+def pose_vec2mat(vec, dtype=np.float32):
+    """[n,6] ``[rz,ry,rx,tx,ty,tz]`` -> [n,4,4] (geo_utils.py:93-119)."""
+    vec = np.asarray(vec, dtype).reshape(-1, 6)
+    n = vec.shape[0]
+    m = np.zeros((n, 4, 4), dtype)
+    m[:, :3, :3] = euler2mat(vec[:, 0], vec[:, 1], vec[:, 2], dtype)
+    m[:, :3, 3] = vec[:, 3:6]
+    m[:, 3, 3] = 1
+    return m
+
+
+def mat2pose_vec(m):
+    """Inverse of pose_vec2mat for |ry| < pi/2 (float64): with R = Rx.Ry.Rz,
+    R[0,2] = sin y, R[0,1] = -cos y sin z, R[1,2] = -sin x cos y."""
+    m = np.asarray(m, np.float64).reshape(-1, 4, 4)
+    y = np.arcsin(np.clip(m[:, 0, 2], -1.0, 1.0))
+    z = np.arctan2(-m[:, 0, 1], m[:, 0, 0])
+    x = np.arctan2(-m[:, 1, 2], m[:, 2, 2])
+    return np.concatenate([np.stack([z, y, x], -1), m[:, :3, 3]], -1)
+
+
+# ---- stitch + writer (test_kitti_pose.py:136-153) -----------------------------------------
+def stitch_trajectory(poses, mat_dtype=np.float32):
+    """poses [Nw,2,6] (row 0 = tgt->src0, row 1 = tgt->src1 of window w, tgt = frame w+1)
+    -> list of Nw+2 float64 4x4 camera poses, first = identity.
+
+    First window contributes T(tgt->src0); every window contributes inv(T(tgt->src1))
+    (test_kitti_pose.py:141-145); the chain is float64 (``np.eye(4).astype(float)``, :118)."""
+    poses = np.asarray(poses, np.float32)
+    steps = []
+    for w in range(poses.shape[0]):
+        three = np.insert(poses[w], 1, np.zeros((1, 6), np.float32), axis=0)      # :141
+        mats = pose_vec2mat(three, mat_dtype)                                      # :142
+        if w == 0:
+            steps.append(mats[0])                                                  # :144
+        steps.append(np.linalg.inv(mats[2]))                                       # :145
+    prev = np.eye(4).astype(float)
+    out = [prev]
+    for p in steps:                                                                # :147-149
+        prev = np.dot(prev, p)
+        out.append(prev)
+    return out
+
+
+def write_kitti_poses(path, mats):
+    """first 3 rows, 12 x str(float) per line (test_kitti_pose.py:150-153)."""
+    with open(path, "w") as f:
+        for p in mats:
+            f.write("%s\n" % " ".join([str(float(x)) for x in np.asarray(p)[:3, :].reshape(12)]))
+
+
+def read_kitti_poses(path):
+    a = np.loadtxt(path).reshape(-1, 3, 4)
+    m = np.tile(np.eye(4), (a.shape[0], 1, 1))
+    m[:, :3, :] = a
+    return m
+
+
+def relative_pose_vectors(abs_poses):
+    """Ground-truth poses -> the [Nw,2,6] tensor a perfect network would emit, i.e. the inverse
+    of stitch_trajectory: M(tgt->src0) = P_w^-1 P_{w+1}, M(tgt->src1) = P_{w+2}^-1 P_{w+1}."""
+    P = np.asarray(abs_poses, np.float64)
+    nw = P.shape[0] - 2
+    out = np.zeros((nw, 2, 6))
+    for w in range(nw):
+        out[w, 0] = mat2pose_vec(np.linalg.inv(P[w]).dot(P[w + 1]))[0]
+        out[w, 1] = mat2pose_vec(np.linalg.inv(P[w + 2]).dot(P[w + 1]))[0]
+    return out
+
+
+# ---- window sharding + gather --------------------------------------------------------------
+def is_valid_sample(n_frames, tgt_idx, seq_length=3):
+    """utils/common_utils.py:16-28 for a single drive."""
+    off = int((seq_length - 1) / 2)
+    return tgt_idx - off >= 0 and tgt_idx + off < n_frames
+
+
+def shard_windows(n_windows, world, rank):
+    """contiguous range of rank: [r*ceil(Nw/R), min((r+1)*ceil(Nw/R), Nw))"""
+    per = -(-n_windows // world)
+    lo = min(rank * per, n_windows)
+    return lo, min(lo + per, n_windows)
+
+
+def run_shard(infer_fn, load_windows, lo, hi, batch_size):
+    """Run windows [lo,hi) in batches; the last batch is padded by repeating its last window
+    and the padded outputs are dropped (the reference's complete_batch_size,
+    utils/common_utils.py:8-13, would append duplicate poses for B>1; parity is defined on
+    B=1 semantics)."""
+    out = np.zeros((hi - lo, 2, 6), np.float32)
+    for s in range(lo, hi, batch_size):
+        e = min(s + batch_size, hi)
+        img, flow, seg = load_windows(s, e)
+        n = e - s
+        if n < batch_size:
+            pad = batch_size - n
+            img = np.concatenate([img, np.repeat(img[-1:], pad, 0)])
+            flow = np.concatenate([flow, np.repeat(flow[-1:], pad, 0)])
+            seg = np.concatenate([seg, np.repeat(seg[-1:], pad, 0)])
+        out[s - lo:e - lo] = np.asarray(infer_fn(img, flow, seg))[:n]
+    return out
+
+
+def gather_poses(local, n_windows, world, rank, device=None):
+    """All ranks -> [Nw,2,6] on every rank.  One all_gather of equal padded counts through
+    torch.distributed (backend "nccl" = RCCL on the GPUs, "gloo" in the CPU tests)."""
+    if world == 1:
+        return np.asarray(local, np.float32)
+    import torch
+    import torch.distributed as dist
+    per = -(-n_windows // world)
+    buf = torch.zeros((per, 2, 6), dtype=torch.float32)
+    buf[:local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local, np.float32))
+    if device is not None:
+        buf = buf.to(device)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    full = torch.cat(parts, 0).cpu().numpy()
+    return full[:n_windows]
+
+
+def run_sequence(infer_fn, load_windows, n_frames, batch_size, rank=0, world=1, device=None):
+    """The driver loop of test_kitti_pose.py:133-149, sharded: returns the Nf 4x4 poses on
+    every rank (the stitch is cheap and sequential; rank 0 writes the file)."""
+    n_windows = n_frames - 2
+    lo, hi = shard_windows(n_windows, world, rank)
+    local = run_shard(infer_fn, load_windows, lo, hi, batch_size)
+    poses = gather_poses(local, n_windows, world, rank, device)
+    return stitch_trajectory(poses), poses
+
+
+# ---- on-disk inputs (data_loader.py:241-325; doc/preprocessing.md:50-114) -------------------
+def kitti_window_loader(concat_img_dir, seq, n_frames, H, W):
+    """load_windows(s, e) over the reference's dump: '<seq>/<frame>.jpg' = hstack(src0,tgt,src1)
+    (data/preprocess.py:61-66), '-flownet2.npy' (4,H,W,2) f32, '-seglabel.npy' (3,H,W,1) f32;
+    file naming test_kitti_pose.py:44-49.  Window w has tgt frame w+1."""
+    from PIL import Image
+    d = os.path.join(concat_img_dir, "%.2d" % seq)
+
+    def load(s, e):
+        imgs, flows, segs = [], [], []
+        for w in range(s, e):
+            stem = os.path.join(d, "%.6d" % (w + 1))
+            im = np.asarray(Image.open(stem + ".jpg").convert("RGB"), np.uint8)
+            if im.shape != (H, 3 * W, 3):
+                raise ValueError("%s.jpg is %s, expected %s" % (stem, im.shape, (H, 3 * W, 3)))
+            imgs.append(im)
+            flows.append(np.load(stem + "-flownet2.npy").astype(np.float32).reshape(4, H, W, 2))
+            segs.append(np.load(stem + "-seglabel.npy").astype(np.float32).reshape(3, H, W, 1))
+        return np.stack(imgs), np.stack(flows), np.stack(segs)
+    return load
+
+
+def synthetic_window_loader(H, W, seed=None):
+    from . import synth
+
+    def load(s, e):
+        return synth.make_inputs(e - s, H, W, seed=synth.SEED if seed is None else seed, first_window=s)
+    return load

@@ -198,3 +198,18 @@ def test_error_behaviour():
         Engine(cfg, 62, 96, 1)
     with pytest.raises(NameError):
         DAVO("v1-sharedNN-dilatedPoseNN-se_spp_flow").setup_inference(64, 96, "davo")
+
+
+def test_sequence_driver_on_gpu(tmp_path, c_oracle):
+    """config-1 plumbing on the GPU: a 13-frame synthetic sequence through run_kitti_pose ->
+    13-line trajectory file that matches the oracle-driven stitch."""
+    from davo_amd import run_kitti_pose, sequence as S
+    run_kitti_pose.main(["--synthetic", "13", "--output_dir", str(tmp_path), "--test_seq", "3",
+                         "--batch_size", "4", "--img_height", "64", "--img_width", "96"])
+    got = S.read_kitti_poses(str(tmp_path / "03-pred_kitti_pose.txt"))
+    cfg = parse_version(FLAGSHIP_VERSION)
+    weights = synth.make_weights(cfg)
+    infer = lambda img, flow, seg: c_oracle.forward(cfg, img, flow, seg, weights)   # noqa: E731
+    want, _ = S.run_sequence(infer, S.synthetic_window_loader(64, 96), 13, 4)
+    assert got.shape == (13, 4, 4)
+    assert np.abs(got - np.array(want)).max() < 2e-4
