@@ -42,6 +42,7 @@ struct ConvParams {
     int M;                // images * Hout * Wout
     int nchunks, Kpad, ntaps;
     int ntiles_n;
+    int mtile0;           // first 128-row M tile of this launch (a layer may be split in two launches)
     int relu;
     // grouped launch (blockIdx.y = group): per-group strides
     int g_x_coff, g_y_coff;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     const int wm = wid / T::WN, wn = wid % T::WN;
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = tile % p.ntiles_n, mtile = tile / p.ntiles_n;
+    const int ntile = tile % p.ntiles_n, mtile = p.mtile0 + tile / p.ntiles_n;
     const int grp = blockIdx.y;
     const float* __restrict__ xg = p.x + p.x_coff + grp * p.g_x_coff;
     const float* __restrict__ wg = p.w + grp * p.g_w + (long)ntile * BN * p.Kpad;

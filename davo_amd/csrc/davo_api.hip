@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -84,6 +85,7 @@ struct davo_ctx {
     int act_ch[7];
     int packed_ld = 8;
     int last_B = 0;
+    int last_plan[7][2] = {};                  // per layer, per launch: mtiles*1000 + BN (reported by the bench)
     // host-API staging
     void *s_img = nullptr, *s_flow = nullptr, *s_seg = nullptr, *s_pose = nullptr;
     // profiling
@@ -157,18 +159,76 @@ hipError_t launch_conv(int KS, int stride, int BN, const ConvParams& p, dim3 gri
     return hipErrorInvalidValue;
 }
 
-// the seven PoseNN launches, each under its own kernel name (LAYER tag)
-hipError_t launch_layer(int layer, int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
-    switch (layer) {
-        case 0: return launch_conv_t<7, 2, 32, 1>(p, grid, s);
-        case 1: return launch_conv_t<5, 2, 32, 2>(p, grid, s);
-        case 2: return launch_conv_t<3, 1, 64, 3>(p, grid, s);
-        case 3: return launch_conv_t<3, 1, 128, 4>(p, grid, s);
-        case 4: return launch_conv_t<3, 1, 128, 5>(p, grid, s);
-        case 5: return BN == 128 ? launch_conv_t<3, 1, 128, 6>(p, grid, s) : launch_conv_t<3, 1, 64, 6>(p, grid, s);
-        case 6: return launch_conv_t<3, 2, 128, 7>(p, grid, s);
+// the seven PoseNN layers, each under its own kernel name (LAYER tag); BN is chosen per launch
+template <int KS, int STRIDE, int LAYER>
+hipError_t launch_tagged(int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
+    switch (BN) {
+        case 32: return launch_conv_t<KS, STRIDE, 32, LAYER>(p, grid, s);
+        case 64: return launch_conv_t<KS, STRIDE, 64, LAYER>(p, grid, s);
+        case 128: return launch_conv_t<KS, STRIDE, 128, LAYER>(p, grid, s);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_layer(int layer, int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
+    switch (layer) {
+        case 0: return launch_tagged<7, 2, 1>(BN, p, grid, s);
+        case 1: return launch_tagged<5, 2, 2>(BN, p, grid, s);
+        case 2: return launch_tagged<3, 1, 3>(BN, p, grid, s);
+        case 3: return launch_tagged<3, 1, 4>(BN, p, grid, s);
+        case 4: return launch_tagged<3, 1, 5>(BN, p, grid, s);
+        case 5: return launch_tagged<3, 1, 6>(BN, p, grid, s);
+        case 6: return launch_tagged<3, 2, 7>(BN, p, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- launch planning ----------------------------------------------------------------------
+// Workgroups of one launch all take the same time, and the dispatcher refills both slots of a
+// CU together, so a grid that is not a whole number of rounds (256 CUs x resident workgroups)
+// pays for a full last round: at B = 32 the 3,328 tiles of cnv5/cnv6 are 6.5 rounds of 512 and
+// ran in the time of 7.  A layer is therefore issued as a main launch of whole rounds at the
+// widest N tile plus, when it pays, a remainder launch with a narrower N tile (more, shorter
+// workgroups) that again fills whole rounds.  Costs are in units of one round of 128x128 tiles.
+struct Launch { int mtile0, mtiles, BN; };
+
+int slots_for(int BN) { return 256 * (BN == 32 ? 3 : 2); }         // LDS 46 / 55 / 74 KB per workgroup
+// time of one round (every CU full) relative to a round of 128x128 tiles: resident workgroups
+// per CU x tile area / measured relative efficiency of the narrower tiles
+double tile_cost(int BN) { return BN == 128 ? 1.0 : BN == 64 ? 0.5 / 0.92 : 0.375 / 0.75; }
+
+double rounds_cost(long tiles, int BN) {
+    const long s = slots_for(BN);
+    return (double)((tiles + s - 1) / s) * tile_cost(BN);
+}
+
+std::vector<Launch> plan_layer(int mtiles, int npad, int groups) {
+    int bmax = npad % 128 == 0 ? 128 : npad % 64 == 0 ? 64 : 32;
+    // tuning overrides (measurement only): DAVO_FORCE_BN=32|64|128 -> one launch at that N tile,
+    // DAVO_PLAN=single -> one launch at the widest N tile
+    if (const char* e = getenv("DAVO_FORCE_BN")) {
+        const int bn = atoi(e);
+        if ((bn == 32 || bn == 64 || bn == 128) && npad % bn == 0) return {{0, mtiles, bn}};
+    }
+    if (const char* e = getenv("DAVO_PLAN"))
+        if (!strcmp(e, "single")) return {{0, mtiles, bmax}};
+    std::vector<Launch> best;
+    double best_cost = 1e30;
+    for (int bn = bmax; bn >= 32; bn >>= 1) {                          // one launch
+        const double c = rounds_cost((long)mtiles * (npad / bn) * groups, bn);
+        if (c < best_cost - 1e-9) { best_cost = c; best = {{0, mtiles, bn}}; }
+    }
+    const long per_m = (long)(npad / bmax) * groups;                   // tiles per M tile at bmax
+    const long s = slots_for(bmax);
+    const int main_m = (int)(((long)mtiles * per_m / s) * s / per_m);  // whole rounds only
+    if (main_m > 0 && main_m < mtiles && (main_m * per_m) % s == 0) {
+        const double cm = rounds_cost(main_m * per_m, bmax);
+        for (int bn = bmax; bn >= 32; bn >>= 1) {
+            const double c = cm + rounds_cost((long)(mtiles - main_m) * (npad / bn) * groups, bn) + 0.02;
+            if (c < best_cost - 1e-9) { best_cost = c; best = {{0, main_m, bmax}, {main_m, mtiles - main_m, bn}}; }
+        }
+    }
+    return best;
 }
 
 int pick_bn(int cout) { return cout <= 32 ? 32 : (cout % 128 == 0 ? 128 : (cout <= 64 ? 64 : 128)); }
@@ -400,9 +460,17 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
         p.g_w = (long)L.npad * L.kpad; p.g_bias = L.npad;
     }
     const int mtiles = (p.M + BM - 1) / BM;
-    dim3 grid(mtiles * p.ntiles_n, L.groups);
-    ProfScope ps(c, L.label);
-    HIP_TRY(c, launch_layer(li, L.BN, p, grid, c->stream));
+    const std::vector<Launch> plan = plan_layer(mtiles, L.npad, L.groups);
+    c->last_plan[li][0] = c->last_plan[li][1] = 0;
+    for (size_t i = 0; i < plan.size(); ++i) {
+        p.mtile0 = plan[i].mtile0;
+        p.ntiles_n = L.npad / plan[i].BN;
+        dim3 grid(plan[i].mtiles * p.ntiles_n, L.groups);
+        const std::string label = i == 0 ? std::string(L.label) : std::string(L.label) + ".rem";
+        ProfScope ps(c, label.c_str());
+        HIP_TRY(c, launch_layer(li, plan[i].BN, p, grid, c->stream));
+        c->last_plan[li][i] = plan[i].mtiles * 1000 + plan[i].BN;
+    }
     return DAVO_OK;
 }
 
@@ -714,6 +782,14 @@ int davo_profile_entry(davo_ctx* c, int i, char* name, int name_len, int* launch
     if (name && name_len > 0) { strncpy(name, pe.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
     if (launches) *launches = pe.launches;
     if (total_ms) *total_ms = pe.total_ms;
+    return DAVO_OK;
+}
+
+int davo_last_plan(davo_ctx* c, int layer, int launch, int* mtiles, int* bn) {
+    if (!c || layer < 0 || layer > 6 || launch < 0 || launch > 1) return DAVO_ERR_INVALID;
+    const int v = c->last_plan[layer][launch];
+    if (mtiles) *mtiles = v / 1000;
+    if (bn) *bn = v % 1000;
     return DAVO_OK;
 }
 

@@ -133,6 +133,16 @@ class Engine:
             i += 1
         return out
 
+    def last_plan(self, layer):
+        """[(mtiles, BN), ...] of the launches the last forward used for conv layer 0..6."""
+        out = []
+        for k in (0, 1):
+            m, bn = ctypes.c_int(0), ctypes.c_int(0)
+            self._check(self._L.davo_last_plan(self._ctx, layer, k, ctypes.byref(m), ctypes.byref(bn)))
+            if m.value:
+                out.append((m.value, bn.value))
+        return out
+
     def debug_read(self, tensor, shape):
         out = np.empty(shape, np.float32)
         self._check(self._L.davo_debug_read(self._ctx, tensor.encode(), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), out.size))

@@ -100,6 +100,12 @@ int davo_profile_reset(davo_ctx* ctx);
 int davo_profile_entry(davo_ctx* ctx, int i, char* name, int name_len, int* launches,
                        double* total_ms);
 
+/* How the LAST forward issued conv layer `layer` (0..6 = cnv1..cnv7): launch 0 is the main launch,
+ * launch 1 the remainder launch with a narrower N tile (mtiles = 0 if there was none).  A launch
+ * covers `mtiles` 128-row M tiles x all output channels, in N tiles of `bn`.  bench.py uses it to
+ * price the FLOPs of the launch it puts on the roofline. */
+int davo_last_plan(davo_ctx* ctx, int layer, int launch, int* mtiles, int* bn);
+
 /* ---- test hooks -------------------------------------------------------------------------
  * impl 0 = MFMA implicit-GEMM kernels (default, the product path);
  * impl 1 = one-thread-per-output direct convolution in HIP on the reference's own tensor
