@@ -15,7 +15,7 @@ EXPORTS = (
     "davo_create", "davo_load_weight", "davo_weights_missing", "davo_forward", "davo_forward_device",
     "davo_last_error", "davo_destroy", "davo_device_malloc", "davo_device_free", "davo_memcpy_h2d",
     "davo_memcpy_d2h", "davo_synchronize", "davo_set_stream", "davo_profile_enable",
-    "davo_profile_reset", "davo_profile_entry", "davo_last_plan", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
+    "davo_profile_reset", "davo_profile_entry", "davo_last_plan", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
 )
 
 
@@ -25,7 +25,7 @@ class DavoVariant(ctypes.Structure):
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in ("davo_api.hip", "conv_igemm.h", "prologue.h")] + \
+    return [os.path.join(CSRC, f) for f in ("davo_api.hip", "conv_igemm.h", "conv_igemm_h3.h", "prologue.h")] + \
            [os.path.join(INCLUDE, "davo_hip.h")]
 
 
@@ -75,9 +75,10 @@ def lib():
     L.davo_profile_reset.argtypes = [vp]
     L.davo_profile_entry.argtypes = [vp, i, ctypes.c_char_p, i, ctypes.POINTER(i), ctypes.POINTER(ctypes.c_double)]
     L.davo_last_plan.argtypes = [vp, i, i, ctypes.POINTER(i), ctypes.POINTER(i)]
+    L.davo_set_precision.argtypes = [vp, i]
     L.davo_set_impl.argtypes = [vp, i]
     L.davo_debug_read.argtypes = [vp, ctypes.c_char_p, f32p, ctypes.c_size_t]
-    L.davo_conv2d_same.argtypes = [i, f32p, i, i, i, i, f32p, i, i, f32p, i, i, i, f32p, ctypes.c_char_p, i]
+    L.davo_conv2d_same.argtypes = [i, f32p, i, i, i, i, f32p, i, i, f32p, i, i, i, i, f32p, ctypes.c_char_p, i]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("davo_last_error", "davo_destroy"):

@@ -1,0 +1,248 @@
+// conv_igemm_h3.h — the same implicit-GEMM convolution as conv_igemm.h, on the fp16 matrix
+// cores with float32-grade accuracy ("f16x3").
+//
+// FP32 MFMA runs at 1/16 of the fp16 rate on gfx950 and there is no xf32/TF32 path, so every
+// float32 operand is split into two fp16 numbers
+//
+//     a = ah + al * 2^-11,   ah = fp16(a),   al = fp16((a - ah) * 2^11)      (22 significant bits)
+//
+// and a product is evaluated as three fp16 MFMA products accumulated in float32:
+//
+//     a*b  ~=  ah*bh + 2^-11 * (ah*bl + al*bh)                   (the dropped al*bl term is 2^-22)
+//
+// ah*bh goes to one accumulator, the two cross terms to a second one that is scaled once in the
+// epilogue.  Each fp16 product is exact in float32 (11 x 11 bits), so the only loss is the 2^-22
+// representation error of the operands: measured end to end the 6-DoF outputs differ from the
+// float64 oracle by ~1e-7 relative, like the FP32-MFMA path, at 3 MFMA passes of 32 cycles per
+// K=16 instead of 8 passes of 64 cycles (5.3x less matrix-pipe time).
+//
+// Activations are STORED in the split form by the producing kernel's epilogue — 4 bytes per
+// element, the same HBM bytes as float32 — in a channel-blocked layout: per pixel, per block of
+// CB = min(C,32) channels, CB hi halves followed by CB lo halves.  A K-chunk of 32 k-elements
+// (one tap x 32 channels, or 32/C taps when C < 32) is then one 128-byte LDS row
+// [32 hi | 32 lo], read as four ds_read_b128 fragments per 32-row MFMA tile.  The k order is
+// channel-block major, tap minor, so a workgroup revisits the same 32-channel slice of its
+// pixels for all taps before moving on (L2 / L1 locality of the dilated gather).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_igemm.h"
+
+namespace davo {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+struct ConvParamsH {
+    const uint8_t* x;       // split-fp16 blocked activation
+    const uint8_t* w;       // packed weights: [Npad][nchunks][32 hi | 32 lo] halves (128 B per chunk)
+    const float* bias;      // [Npad]
+    uint8_t* y;             // output: float32 NHWC (y_mode 0) or split-fp16 blocked (y_mode 1)
+    const uint8_t* zeros;   // >= 16 zero bytes: what a padded (out-of-image) tap reads
+    int Hin, Win, Hout, Wout;
+    long x_pix_bytes;       // bytes per input pixel (all channels of the tensor x 4)
+    int x_boff;             // byte offset inside a pixel of the first channel block used
+    int cb_log2;            // CB = channels per block = min(Cin, 32)
+    int tpc_log2;           // taps per chunk = 32 / CB
+    int cpb;                // chunks per channel block = ceil(ntaps / taps per chunk)
+    int nchunks;
+    long w_row_bytes;       // nchunks * 128
+    int y_mode, y_ld, y_coff, Cout;
+    int pad_t, pad_l, rate;
+    int M, ntaps, ntiles_n, mtile0, relu;
+    int g_x_boff, g_y_coff;
+    long g_w, g_bias;
+};
+
+constexpr int LDB = 144;        // LDS row: 128 data bytes + 16 pad (conflict-free b128 fragment reads)
+
+template <int WM, int WN, int TM, int TN> struct TileH {
+    static constexpr int THREADS = WM * WN * 64;
+    static constexpr int BMH = WM * TM * 32;
+    static constexpr int BNH = WN * TN * 32;
+    static constexpr int A_LOADS = BMH * 8 / THREADS;
+    static constexpr int B_LOADS = BNH * 8 / THREADS;
+    static constexpr int ROWS_PER_PASS = THREADS / 8;
+    static constexpr int LDS_BYTES = 2 * (BMH + BNH) * LDB;
+    static_assert(A_LOADS >= 1 && A_LOADS <= 4 && B_LOADS >= 1 && B_LOADS <= 4, "staging shape");
+};
+
+__device__ __forceinline__ half8 lds_frag(const uint8_t* p) {
+    return *reinterpret_cast<const half8*>(p);
+}
+
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN) > 4 ? 2 : 2)
+void conv_igemm_h3(ConvParamsH p) {
+    using T = TileH<WM, WN, TM, TN>;
+    constexpr int BMH = T::BMH, BNH = T::BNH;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_h[];
+    uint8_t* As = smem_h;                              // [2][BMH][LDB]
+    uint8_t* Bs = smem_h + 2 * BMH * LDB;              // [2][BNH][LDB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = tile % p.ntiles_n, mtile = p.mtile0 + tile / p.ntiles_n;
+    const int grp = blockIdx.y;
+    const uint8_t* __restrict__ xg = p.x + p.x_boff + grp * p.g_x_boff;
+    const uint8_t* __restrict__ wg = p.w + grp * p.g_w + (long)ntile * BNH * p.w_row_bytes;
+    const float* __restrict__ bg = p.bias + grp * p.g_bias + ntile * BNH;
+
+    // ---- staging assignment: thread -> (row r0 + ROWS_PER_PASS*j, 16-byte unit u of the 128-byte row)
+    // unit u: plane = u>>2 (0 = hi, 1 = lo), k-elements 8*(u&3) .. +7 of the chunk
+    const int r0 = tid >> 3, u = tid & 7;
+    int iy0[T::A_LOADS], ix0[T::A_LOADS], pix0[T::A_LOADS];
+#pragma unroll
+    for (int j = 0; j < T::A_LOADS; ++j) {
+        const int m = mtile * BMH + r0 + T::ROWS_PER_PASS * j;
+        if (m < p.M) {
+            const int hw = p.Hout * p.Wout;
+            const int n = m / hw, rem = m - n * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            iy0[j] = oy * STRIDE - p.pad_t;
+            ix0[j] = ox * STRIDE - p.pad_l;
+            pix0[j] = n * p.Hin * p.Win;
+        } else {
+            iy0[j] = -(1 << 28);
+            ix0[j] = 0;
+            pix0[j] = 0;
+        }
+    }
+    const int cb = 1 << p.cb_log2;
+    const int e0 = (u & 3) * 8;                              // first k-element of this unit
+    const int tap_in_chunk = e0 >> p.cb_log2;                // which of the chunk's taps it belongs to
+    const int unit_boff = (u >> 2) * (cb * 2) + (e0 & (cb - 1)) * 2;   // plane + channel offset in block
+    const int ldsoff = r0 * LDB + u * 16;
+
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    ra1 = ra2 = ra3 = rb1 = rb2 = rb3 = make_uint4(0, 0, 0, 0);
+
+#define H3_LOAD_A(j_, dst_)                                                                        \
+    if constexpr (T::A_LOADS > j_) {                                                               \
+        const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
+        const bool ok = tap_ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win; \
+        const long off = (long)(pix0[j_] + iy * p.Win + ix) * p.x_pix_bytes + coff;                \
+        dst_ = *reinterpret_cast<const uint4*>(ok ? xg + off : p.zeros);                           \
+    }
+#define H3_LOAD_B(j_, dst_)                                                                        \
+    if constexpr (T::B_LOADS > j_)                                                                 \
+        dst_ = *reinterpret_cast<const uint4*>(wrow + (long)(T::ROWS_PER_PASS * j_) * p.w_row_bytes);
+#define H3_LOAD_CHUNK(q_)                                                                          \
+    {                                                                                              \
+        const int cblk = (q_) / p.cpb, tq = (q_) - cblk * p.cpb;                                   \
+        const int tap = (tq << p.tpc_log2) + tap_in_chunk;                                         \
+        const int ky = tap / KS, kx = tap - ky * KS;                                               \
+        const int dy = ky * p.rate, dx = kx * p.rate;                                              \
+        const bool tap_ok = tap < p.ntaps;                                                         \
+        const int coff = cblk * (cb * 4) + unit_boff;                                              \
+        H3_LOAD_A(0, ra0) H3_LOAD_A(1, ra1) H3_LOAD_A(2, ra2) H3_LOAD_A(3, ra3)                    \
+        const uint8_t* wrow = wg + (long)r0 * p.w_row_bytes + (long)(q_) * 128 + u * 16;           \
+        H3_LOAD_B(0, rb0) H3_LOAD_B(1, rb1) H3_LOAD_B(2, rb2) H3_LOAD_B(3, rb3)                    \
+    }
+#define H3_STORE_CHUNK(buf_)                                                                       \
+    {                                                                                              \
+        uint8_t* a_ = As + (buf_) * BMH * LDB + ldsoff;                                            \
+        uint8_t* b_ = Bs + (buf_) * BNH * LDB + ldsoff;                                            \
+        *reinterpret_cast<uint4*>(a_) = ra0;                                                       \
+        if constexpr (T::A_LOADS > 1) *reinterpret_cast<uint4*>(a_ + 1 * T::ROWS_PER_PASS * LDB) = ra1; \
+        if constexpr (T::A_LOADS > 2) *reinterpret_cast<uint4*>(a_ + 2 * T::ROWS_PER_PASS * LDB) = ra2; \
+        if constexpr (T::A_LOADS > 3) *reinterpret_cast<uint4*>(a_ + 3 * T::ROWS_PER_PASS * LDB) = ra3; \
+        *reinterpret_cast<uint4*>(b_) = rb0;                                                       \
+        if constexpr (T::B_LOADS > 1) *reinterpret_cast<uint4*>(b_ + 1 * T::ROWS_PER_PASS * LDB) = rb1; \
+        if constexpr (T::B_LOADS > 2) *reinterpret_cast<uint4*>(b_ + 2 * T::ROWS_PER_PASS * LDB) = rb2; \
+        if constexpr (T::B_LOADS > 3) *reinterpret_cast<uint4*>(b_ + 3 * T::ROWS_PER_PASS * LDB) = rb3; \
+    }
+    // one 32-k chunk = two K=16 MFMA steps; per step and output tile: hi*hi -> main,
+    // hi*lo and lo*hi -> cross
+#define H3_COMPUTE(buf_)                                                                           \
+    {                                                                                              \
+        const uint8_t* a = As + (buf_) * BMH * LDB + (wm * TM * 32 + li) * LDB + 16 * lh;          \
+        const uint8_t* b = Bs + (buf_) * BNH * LDB + (wn * TN * 32 + li) * LDB + 16 * lh;          \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                            \
+            half8 ah[TM], al[TM], bh[TN], bl[TN];                                                  \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                       \
+                ah[i] = lds_frag(a + i * 32 * LDB + 32 * s);                                       \
+                al[i] = lds_frag(a + i * 32 * LDB + 64 + 32 * s);                                  \
+            }                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+                bh[j] = lds_frag(b + j * 32 * LDB + 32 * s);                                       \
+                bl[j] = lds_frag(b + j * 32 * LDB + 64 + 32 * s);                                  \
+            }                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0); \
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0); \
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0); \
+                }                                                                                  \
+        }                                                                                          \
+    }
+
+    f32x16 accm[TM][TN], accx[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+    H3_LOAD_CHUNK(0)
+    H3_STORE_CHUNK(0)
+    __syncthreads();
+
+    for (int q = 0; q + 1 < p.nchunks; ++q) {
+        const int buf = q & 1;
+        H3_LOAD_CHUNK(q + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        H3_COMPUTE(buf)
+        __builtin_amdgcn_sched_barrier(0);
+        H3_STORE_CHUNK(buf ^ 1)
+        __syncthreads();
+    }
+    H3_COMPUTE((p.nchunks - 1) & 1)
+
+    // ---- epilogue: combine, bias, ReLU; store float32 or re-split for the next layer ---------
+    const int ocb_log2 = p.y_ld >= 32 ? 5 : (p.y_ld == 16 ? 4 : 3);
+    const int ocb = 1 << ocb_log2;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ncol = wn * TN * 32 + j * 32 + li;
+        const int n = ntile * BNH + ncol;
+        const float bv = bg[ncol];
+        const bool n_ok = n < p.Cout;
+        const int ng = p.y_coff + grp * p.g_y_coff + n;              // channel in the output tensor
+        const long cbyte = (long)(ng >> ocb_log2) * (ocb * 4) + (ng & (ocb - 1)) * 2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = mtile * BMH + row;
+                float v = accm[i][j][r] + accx[i][j][r] * (1.0f / 2048.0f) + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (n_ok && m < p.M) {
+                    if (p.y_mode == 0) {
+                        reinterpret_cast<float*>(p.y)[(long)m * p.y_ld + ng] = v;
+                    } else {
+                        v = fminf(fmaxf(v, -65504.f), 65504.f);     // fp16 range; see DESIGN.md
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+                        uint8_t* o = p.y + (long)m * p.y_ld * 4 + cbyte;
+                        *reinterpret_cast<_Float16*>(o) = hi;
+                        *reinterpret_cast<_Float16*>(o + ocb * 2) = lo;
+                    }
+                }
+            }
+    }
+}
+
+#undef H3_LOAD_A
+#undef H3_LOAD_B
+#undef H3_LOAD_CHUNK
+#undef H3_STORE_CHUNK
+#undef H3_COMPUTE
+
+}  // namespace davo

@@ -20,6 +20,7 @@
 
 #include "../../include/davo_hip.h"
 #include "conv_igemm.h"
+#include "conv_igemm_h3.h"
 #include "prologue.h"
 
 using namespace davo;
@@ -39,6 +40,10 @@ struct ConvLayer {
     int BN, npad, kpad, nchunks, groups;
     float* d_w = nullptr;          // [groups][npad][kpad]
     float* d_b = nullptr;          // [groups][npad]
+    // f16x3 path (conv_igemm_h3.h): channel-blocked k order, split-fp16 packed weights
+    int cb_log2 = 0, tpc_log2 = 0, cpb = 0, nchunks_h = 0, npad_h = 0, tile_h = 0;
+    uint8_t* d_wh = nullptr;       // [groups][npad_h][nchunks_h][32 hi | 32 lo] halves
+    float* d_bh = nullptr;         // [groups][npad_h]
 };
 
 struct ProfEntry {
@@ -69,6 +74,9 @@ struct davo_ctx {
     int device = 0, H = 0, W = 0, max_batch = 0;
     Variant v{};
     int impl = 0;
+    int precision = 1;                         // 0 = FP32 MFMA (bit-exact fmaf chains), 1 = f16x3 split (default)
+    bool packed_h_ready = false;
+    int last_precision = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
     std::map<std::string, HostTensor> weights;
@@ -231,6 +239,89 @@ std::vector<Launch> plan_layer(int mtiles, int npad, int groups) {
     return best;
 }
 
+// ---- f16x3 path: tile shapes, weight packing, dispatch --------------------------------------
+// tile id -> (WM, WN, TM, TN): BM = WM*TM*32, BN = WN*TN*32, threads = WM*WN*64
+enum { TILE_128x32 = 0, TILE_256x64 = 1, TILE_256x128 = 2, TILE_128x256 = 3, TILE_128x128 = 4 };
+struct TileShape { int bm, bn, threads, lds; };
+TileShape tile_shape(int t) {
+    switch (t) {
+        case TILE_128x32: return {128, 32, 256, TileH<4, 1, 1, 1>::LDS_BYTES};
+        case TILE_256x64: return {256, 64, 512, TileH<4, 2, 2, 1>::LDS_BYTES};
+        case TILE_256x128: return {256, 128, 512, TileH<4, 2, 2, 2>::LDS_BYTES};
+        case TILE_128x256: return {128, 256, 512, TileH<2, 4, 2, 2>::LDS_BYTES};
+        default: return {128, 128, 256, TileH<2, 2, 2, 2>::LDS_BYTES};
+    }
+}
+
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER>
+hipError_t launch_h3_t(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    using T = TileH<WM, WN, TM, TN>;
+    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(T::THREADS), T::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+template <int KS, int STRIDE, int LAYER>
+hipError_t launch_h3_tile(int tile, const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    switch (tile) {
+        case TILE_128x32: return launch_h3_t<KS, STRIDE, 4, 1, 1, 1, LAYER>(p, grid, s);
+        case TILE_256x64: return launch_h3_t<KS, STRIDE, 4, 2, 2, 1, LAYER>(p, grid, s);
+        case TILE_256x128: return launch_h3_t<KS, STRIDE, 4, 2, 2, 2, LAYER>(p, grid, s);
+        case TILE_128x256: return launch_h3_t<KS, STRIDE, 2, 4, 2, 2, LAYER>(p, grid, s);
+        case TILE_128x128: return launch_h3_t<KS, STRIDE, 2, 2, 2, 2, LAYER>(p, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_layer_h3(int layer, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    switch (layer) {
+        case 0: return launch_h3_tile<7, 2, 1>(tile, p, grid, s);
+        case 1: return launch_h3_tile<5, 2, 2>(tile, p, grid, s);
+        case 2: return launch_h3_tile<3, 1, 3>(tile, p, grid, s);
+        case 3: return launch_h3_tile<3, 1, 4>(tile, p, grid, s);
+        case 4: return launch_h3_tile<3, 1, 5>(tile, p, grid, s);
+        case 5: return launch_h3_tile<3, 1, 6>(tile, p, grid, s);
+        case 6: return launch_h3_tile<3, 2, 7>(tile, p, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+inline void split_f16(float v, _Float16* hi, _Float16* lo) {
+    const _Float16 h = (_Float16)v;
+    *hi = h;
+    *lo = (_Float16)((v - (float)h) * 2048.0f);
+}
+
+// HWIO float32 [KS,KS,Cin_tf,Cout] -> [npad][nchunks][32 hi | 32 lo] halves in the kernel's k
+// order: chunk q = (channel block cblk, tap group tq), element e -> tap = tq*tpc + e/CB,
+// channel = cblk*CB + e%CB.
+void pack_conv_weights_h3(const float* w_tf, int KS, int cin_tf, int cout, const int* chmap, int cin_packed,
+                          int cb_log2, int tpc_log2, int cpb, int nchunks, _Float16* out /*zeroed*/) {
+    const int cb = 1 << cb_log2, ntaps = KS * KS;
+    for (int q = 0; q < nchunks; ++q) {
+        const int cblk = q / cpb, tq = q % cpb;
+        for (int e = 0; e < 32; ++e) {
+            const int tap = (tq << tpc_log2) + (e >> cb_log2);
+            const int cp = cblk * cb + (e & (cb - 1));
+            if (tap >= ntaps || cp >= cin_packed) continue;
+            const int ci = chmap ? chmap[cp] : cp;
+            if (ci < 0 || ci >= cin_tf) continue;
+            const float* src = w_tf + ((size_t)tap * cin_tf + ci) * cout;
+            for (int n = 0; n < cout; ++n) {
+                _Float16* o = out + ((size_t)n * nchunks + q) * 64;
+                split_f16(src[n], o + e, o + 32 + e);
+            }
+        }
+    }
+}
+
 int pick_bn(int cout) { return cout <= 32 ? 32 : (cout % 128 == 0 ? 128 : (cout <= 64 ? 64 : 128)); }
 
 // Re-lay-out HWIO weights [KS,KS,Cin_tf,Cout] -> Wp[npad][kpad], k = tap*cin_packed + c, where
@@ -366,6 +457,14 @@ void init_layer(ConvLayer& L, const char* label, int KS, int stride, int rate, i
     L.npad = (cout + L.BN - 1) / L.BN * L.BN;
     L.kpad = (KS * KS * cin + BK - 1) / BK * BK;
     L.nchunks = L.kpad / BK;
+    const int cb = cin < 32 ? cin : 32;
+    L.cb_log2 = ilog2_exact(cb);
+    L.tpc_log2 = ilog2_exact(32 / cb);
+    L.cpb = (KS * KS + (32 / cb) - 1) / (32 / cb);
+    L.nchunks_h = (cin / cb) * L.cpb;
+    L.tile_h = cout <= 32 ? TILE_128x32 : cout <= 64 ? TILE_256x64 : cout <= 128 ? TILE_256x128 : TILE_128x256;
+    const int bn = tile_shape(L.tile_h).bn;
+    L.npad_h = (cout + bn - 1) / bn * bn;
 }
 
 int build_packed_weights(davo_ctx* c) {
@@ -431,6 +530,56 @@ int build_packed_weights(davo_ctx* c) {
     return DAVO_OK;
 }
 
+int upload_bytes(davo_ctx* c, const void* host, size_t bytes, void** dev) {
+    if (*dev) { HIP_TRY(c, hipFree(*dev)); *dev = nullptr; }
+    HIP_TRY(c, hipMalloc(dev, bytes));
+    HIP_TRY(c, hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+    return DAVO_OK;
+}
+
+// split-fp16 weights for the f16x3 path, same layer structure as build_packed_weights
+int build_packed_weights_h3(davo_ctx* c) {
+    const int c6 = c->v.cnv6_out, cpf = c->v.cin_per_frame;
+    auto W = [&](const std::string& n) -> const HostTensor& { return c->weights.at(n); };
+    int chmap1[8];
+    if (cpf == 5) { const int m[8] = {0, 1, 2, 5, 6, 7, 8, 9}; memcpy(chmap1, m, sizeof m); }
+    else { const int m[8] = {0, 1, 2, 3, 4, 5, -1, -1}; memcpy(chmap1, m, sizeof m); }
+    const char* heads[2] = {"rotation", "translation"};
+    for (int li = 0; li < 7; ++li) {
+        ConvLayer& L = c->L[li];
+        const size_t per_group = (size_t)L.npad_h * L.nchunks_h * 64;
+        std::vector<_Float16> wp(per_group * L.groups, (_Float16)0.0f);
+        std::vector<float> bp((size_t)L.npad_h * L.groups, 0.f);
+        auto pack = [&](const std::string& wname, const std::string& bname, int cin_tf, int cout, const int* chmap,
+                        _Float16* wdst, float* bdst) {
+            pack_conv_weights_h3(W(wname).data.data(), L.KS, cin_tf, cout, chmap, L.cin, L.cb_log2, L.tpc_log2, L.cpb,
+                                 L.nchunks_h, wdst);
+            memcpy(bdst, W(bname).data.data(), cout * sizeof(float));
+        };
+        if (li < 5) {
+            const char* names[5] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5"};
+            const std::string p = std::string("pose_exp_net/") + names[li] + "/";
+            pack(p + "weights", p + "biases", li == 0 ? 2 * cpf : L.cin, L.cout, li == 0 ? chmap1 : nullptr, wp.data(), bp.data());
+        } else if (li == 5) {       // rotation | translation stacked along N
+            for (int h = 0; h < 2; ++h) {
+                const std::string p = std::string("pose_exp_net/pose/") + heads[h] + "/cnv6/";
+                pack(p + "weights", p + "biases", 256, c6, nullptr, wp.data() + (size_t)h * c6 * L.nchunks_h * 64, bp.data() + h * c6);
+            }
+        } else {                    // cnv7: one group per head
+            for (int h = 0; h < 2; ++h) {
+                const std::string p = std::string("pose_exp_net/pose/") + heads[h] + "/cnv7/";
+                pack(p + "weights", p + "biases", c6, 256, nullptr, wp.data() + (size_t)h * per_group, bp.data() + (size_t)h * L.npad_h);
+            }
+        }
+        int rc = upload_bytes(c, wp.data(), wp.size() * sizeof(_Float16), reinterpret_cast<void**>(&L.d_wh));
+        if (rc) return rc;
+        rc = upload(c, bp, &L.d_bh);
+        if (rc) return rc;
+    }
+    c->packed_h_ready = true;
+    return DAVO_OK;
+}
+
 int missing_weights(davo_ctx* c, std::string* names) {
     int n = 0;
     for (auto& nm : c->needed)
@@ -474,6 +623,36 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
     return DAVO_OK;
 }
 
+// f16x3 launch of conv layer li: x and y are split-fp16 blocked tensors (y float32 when y_f32)
+int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int Win, void* y, int y_ld,
+                      bool y_f32, int NB) {
+    const ConvLayer& L = c->L[li];
+    ConvParamsH p{};
+    int Ho, Wo, pt, pl;
+    same_pad(Hin, L.KS, L.stride, L.rate, &Ho, &pt);
+    same_pad(Win, L.KS, L.stride, L.rate, &Wo, &pl);
+    const TileShape ts = tile_shape(L.tile_h);
+    p.x = static_cast<const uint8_t*>(x); p.w = L.d_wh; p.bias = L.d_bh; p.y = static_cast<uint8_t*>(y);
+    p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
+    p.Hin = Hin; p.Win = Win; p.Hout = Ho; p.Wout = Wo;
+    p.x_pix_bytes = (long)x_ch * 4; p.x_boff = 0;
+    p.cb_log2 = L.cb_log2; p.tpc_log2 = L.tpc_log2; p.cpb = L.cpb; p.nchunks = L.nchunks_h;
+    p.w_row_bytes = (long)L.nchunks_h * 128;
+    p.y_mode = y_f32 ? 0 : 1; p.y_ld = y_ld; p.y_coff = 0; p.Cout = L.cout;
+    p.pad_t = pt; p.pad_l = pl; p.rate = L.rate;
+    p.M = NB * Ho * Wo; p.ntaps = L.KS * L.KS; p.ntiles_n = L.npad_h / ts.bn; p.mtile0 = 0; p.relu = 1;
+    if (L.groups == 2) {
+        p.g_x_boff = L.cin * 4; p.g_y_coff = L.cout;
+        p.g_w = (long)L.npad_h * p.w_row_bytes; p.g_bias = L.npad_h;
+    }
+    const int mtiles = (p.M + ts.bm - 1) / ts.bm;
+    dim3 grid(mtiles * p.ntiles_n, L.groups);
+    c->last_plan[li][0] = mtiles * 1000 + ts.bn; c->last_plan[li][1] = 0;
+    ProfScope ps(c, L.label);
+    HIP_TRY(c, launch_layer_h3(li, L.tile_h, p, grid, c->stream));
+    return DAVO_OK;
+}
+
 int run_direct(davo_ctx* c, const char* label, const float* x, int N, int Hin, int Win, int cin, int x_ld,
                int x_coff, const std::string& wname, const std::string& bname, int KS, int cout, int stride,
                int rate, float* y, int y_ld, int y_coff) {
@@ -498,6 +677,8 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     }
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->packed_ready) { int rc = build_packed_weights(c); if (rc) return rc; }
+    const bool h3 = c->impl == 0 && c->precision == 1;
+    if (h3 && !c->packed_h_ready) { int rc = build_packed_weights_h3(c); if (rc) return rc; }
     const int H = c->H, W = c->W, HW = H * W, NB = 2 * B;
     const Variant& v = c->v;
     hipStream_t s = c->stream;
@@ -521,9 +702,14 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     }
     const long nthreads = (long)NB * H * (W / 4);
     c->packed_ld = c->impl == 0 ? 8 : 10;
+    (void)0;
     {
         ProfScope ps(c, "mask_pack");
-        if (c->impl == 0)
+        if (h3)
+            hipLaunchKernelGGL(mask_pack<16>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s,
+                               static_cast<const uint8_t*>(d_img), static_cast<const float*>(d_flow),
+                               static_cast<const float*>(d_seg), c->d_tab, v, B, H, W, c->d_packed);
+        else if (c->impl == 0)
             hipLaunchKernelGGL(mask_pack<8>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s,
                                static_cast<const uint8_t*>(d_img), static_cast<const float*>(d_flow),
                                static_cast<const float*>(d_seg), c->d_tab, v, B, H, W, c->d_packed);
@@ -536,7 +722,15 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     const int c6 = v.cnv6_out;
     float** a = c->d_act;
     int rc;
-    if (c->impl == 0) {
+    if (h3) {
+        if ((rc = run_conv_layer_h3(c, 0, c->d_packed, 8, H, W, a[0], 16, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 3, a[2], 64, c->H2, c->W2, a[3], 128, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 4, a[3], 128, c->H2, c->W2, a[4], 256, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 5, a[4], 256, c->H2, c->W2, a[5], 2 * c6, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, true, NB))) return rc;
+    } else if (c->impl == 0) {
         if ((rc = run_conv_layer(c, 0, c->d_packed, 8, H, W, a[0], 16, NB))) return rc;
         if ((rc = run_conv_layer(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, NB))) return rc;
         if ((rc = run_conv_layer(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, NB))) return rc;
@@ -567,6 +761,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         HIP_TRY(c, hipGetLastError());
     }
     c->last_B = B;
+    c->last_precision = h3 ? 1 : 0;
     return DAVO_OK;
 }
 
@@ -650,6 +845,7 @@ int davo_load_weight(davo_ctx* c, const char* tf_name, const float* data, const 
     int rc = upload(c, t.data, &t.dev);
     if (rc) return rc;
     c->packed_ready = false;
+    c->packed_h_ready = false;
     return DAVO_OK;
 }
 
@@ -711,7 +907,12 @@ void davo_destroy(davo_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->weights) if (kv.second.dev) (void)hipFree(kv.second.dev);
-    for (auto& L : c->L) { if (L.d_w) (void)hipFree(L.d_w); if (L.d_b) (void)hipFree(L.d_b); }
+    for (auto& L : c->L) {
+        if (L.d_w) (void)hipFree(L.d_w);
+        if (L.d_b) (void)hipFree(L.d_b);
+        if (L.d_wh) (void)hipFree(L.d_wh);
+        if (L.d_bh) (void)hipFree(L.d_bh);
+    }
     for (auto p : c->d_act) if (p) (void)hipFree(p);
     void* misc[] = {c->d_zeros, c->d_wpred, c->d_bpred, c->d_partial, c->d_tab, c->d_packed, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
@@ -793,6 +994,12 @@ int davo_last_plan(davo_ctx* c, int layer, int launch, int* mtiles, int* bn) {
     return DAVO_OK;
 }
 
+int davo_set_precision(davo_ctx* c, int precision) {
+    if (!c || (precision != 0 && precision != 1)) return fail(c, DAVO_ERR_INVALID, "precision must be 0 (f32) or 1 (f16x3)");
+    c->precision = precision;
+    return DAVO_OK;
+}
+
 int davo_set_impl(davo_ctx* c, int impl) {
     if (!c || (impl != 0 && impl != 1)) return fail(c, DAVO_ERR_INVALID, "impl must be 0 (mfma) or 1 (direct)");
     c->impl = impl;
@@ -815,11 +1022,30 @@ int davo_debug_read(davo_ctx* c, const char* tensor, float* host_out, size_t n_f
     }
     if (!src) return fail(c, DAVO_ERR_INVALID, "unknown tensor `%s'", tensor);
     if (n != n_floats) return fail(c, DAVO_ERR_INVALID, "`%s' holds %zu floats, caller asked for %zu", tensor, n, n_floats);
-    return davo_memcpy_d2h(c, host_out, src, n * sizeof(float));
+    int rc = davo_memcpy_d2h(c, host_out, src, n * sizeof(float));
+    if (rc) return rc;
+    const bool split = c->last_precision == 1 && t != "att_table" && t != "cnv7";
+    if (split) {       // split-fp16 blocked -> plain float32 NHWC
+        int ch = 8;
+        const char* names[6] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6"};
+        for (int i = 0; i < 6; ++i) if (t == names[i]) ch = c->act_ch[i];
+        const int cb = ch < 32 ? ch : 32;
+        std::vector<float> tmp(ch);
+        const size_t npix = n / ch;
+        for (size_t px = 0; px < npix; ++px) {
+            const _Float16* raw = reinterpret_cast<const _Float16*>(host_out + px * ch);
+            for (int k = 0; k < ch; ++k) {
+                const _Float16* blk = raw + (size_t)(k / cb) * cb * 2;
+                tmp[k] = (float)blk[k % cb] + (float)blk[cb + k % cb] * (1.0f / 2048.0f);
+            }
+            memcpy(host_out + px * ch, tmp.data(), ch * sizeof(float));
+        }
+    }
+    return DAVO_OK;
 }
 
 int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, const float* w, int k, int Cout,
-                     const float* bias, int stride, int rate, int relu, float* y, char* err, int err_len) {
+                     const float* bias, int stride, int rate, int relu, int precision, float* y, char* err, int err_len) {
     auto bad = [&](const char* m, int code) {
         if (err && err_len > 0) { strncpy(err, m, err_len - 1); err[err_len - 1] = 0; }
         return code;
@@ -827,6 +1053,7 @@ int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, c
     const int cl = ilog2_exact(Cin);
     if (!x || !w || !bias || !y) return bad("null pointer", DAVO_ERR_INVALID);
     if (cl < 2) return bad("Cin must be a power of two >= 4", DAVO_ERR_INVALID);
+    if (precision == 1 && cl < 3) return bad("f16x3 needs Cin >= 8", DAVO_ERR_INVALID);
     if (!(k == 1 || k == 3 || k == 5 || k == 7) || !(stride == 1 || stride == 2) || rate < 1)
         return bad("k in {1,3,5,7}, stride in {1,2}, rate >= 1", DAVO_ERR_INVALID);
     if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed", DAVO_ERR_HIP);
@@ -835,28 +1062,77 @@ int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, c
     int Ho, Wo, pt, pl;
     same_pad(H, k, stride, rate, &Ho, &pt);
     same_pad(W, k, stride, rate, &Wo, &pl);
-    std::vector<float> wp((size_t)L.npad * L.kpad, 0.f), bp(L.npad, 0.f);
-    pack_conv_weights(w, k, Cin, Cout, nullptr, Cin, L.npad, L.kpad, wp.data());
-    memcpy(bp.data(), bias, Cout * sizeof(float));
     const size_t nx = (size_t)N * H * W * Cin, ny = (size_t)N * Ho * Wo * Cout;
-    float *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dz = nullptr;
+    std::vector<float> bp(precision == 1 ? L.npad_h : L.npad, 0.f);
+    memcpy(bp.data(), bias, Cout * sizeof(float));
+    std::vector<float> wp;
+    std::vector<_Float16> wph, xh;
+    const void *hx = x, *hw = nullptr;
+    size_t wbytes = 0;
+    if (precision == 1) {
+        wph.assign((size_t)L.npad_h * L.nchunks_h * 64, (_Float16)0.0f);
+        pack_conv_weights_h3(w, k, Cin, Cout, nullptr, Cin, L.cb_log2, L.tpc_log2, L.cpb, L.nchunks_h, wph.data());
+        hw = wph.data(); wbytes = wph.size() * sizeof(_Float16);
+        const int cb = 1 << L.cb_log2;                       // float32 NHWC -> split-fp16 blocked
+        xh.resize(nx * 2);
+        for (size_t px = 0; px < nx / Cin; ++px)
+            for (int ch = 0; ch < Cin; ++ch) {
+                _Float16* blk = xh.data() + px * Cin * 2 + (size_t)(ch / cb) * cb * 2;
+                split_f16(x[px * Cin + ch], blk + ch % cb, blk + cb + ch % cb);
+            }
+        hx = xh.data();
+    } else {
+        wp.assign((size_t)L.npad * L.kpad, 0.f);
+        pack_conv_weights(w, k, Cin, Cout, nullptr, Cin, L.npad, L.kpad, wp.data());
+        hw = wp.data(); wbytes = wp.size() * sizeof(float);
+    }
+    void *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dz = nullptr;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    chk(hipMalloc(reinterpret_cast<void**>(&dx), nx * 4)); chk(hipMalloc(reinterpret_cast<void**>(&dw), wp.size() * 4));
-    chk(hipMalloc(reinterpret_cast<void**>(&db), bp.size() * 4)); chk(hipMalloc(reinterpret_cast<void**>(&dy), ny * 4));
-    chk(hipMalloc(reinterpret_cast<void**>(&dz), 256));
+    chk(hipMalloc(&dx, nx * 4)); chk(hipMalloc(&dw, wbytes));
+    chk(hipMalloc(&db, bp.size() * 4)); chk(hipMalloc(&dy, ny * 4));
+    chk(hipMalloc(&dz, 256));
     if (e == hipSuccess) {
         chk(hipMemset(dz, 0, 256));
-        chk(hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice));
-        chk(hipMemcpy(dw, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+        chk(hipMemcpy(dx, hx, nx * 4, hipMemcpyHostToDevice));
+        chk(hipMemcpy(dw, hw, wbytes, hipMemcpyHostToDevice));
         chk(hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
-        ConvParams p{};
-        p.x = dx; p.w = dw; p.bias = db; p.y = dy; p.zeros = dz;
-        p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.cin_log2 = cl; p.x_ld = Cin; p.y_ld = Cout;
-        p.Cout = Cout; p.pad_t = pt; p.pad_l = pl; p.rate = rate; p.M = N * Ho * Wo;
-        p.nchunks = L.nchunks; p.Kpad = L.kpad; p.ntaps = k * k; p.ntiles_n = L.npad / L.BN; p.relu = relu;
-        dim3 grid((p.M + BM - 1) / BM * p.ntiles_n, 1);
-        chk(launch_conv(k, stride, L.BN, p, grid, nullptr));
+        if (precision == 1) {
+            const TileShape ts = tile_shape(L.tile_h);
+            ConvParamsH p{};
+            p.x = static_cast<const uint8_t*>(dx); p.w = static_cast<const uint8_t*>(dw);
+            p.bias = static_cast<const float*>(db); p.y = static_cast<uint8_t*>(dy);
+            p.zeros = static_cast<const uint8_t*>(dz);
+            p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.x_pix_bytes = (long)Cin * 4;
+            p.cb_log2 = L.cb_log2; p.tpc_log2 = L.tpc_log2; p.cpb = L.cpb; p.nchunks = L.nchunks_h;
+            p.w_row_bytes = (long)L.nchunks_h * 128; p.y_mode = 0; p.y_ld = Cout; p.Cout = Cout;
+            p.pad_t = pt; p.pad_l = pl; p.rate = rate; p.M = N * Ho * Wo; p.ntaps = k * k;
+            p.ntiles_n = L.npad_h / ts.bn; p.relu = relu;
+            dim3 grid((p.M + ts.bm - 1) / ts.bm * p.ntiles_n, 1);
+            hipError_t le = hipErrorInvalidValue;
+            if (stride == 1) {
+                if (k == 1) le = launch_h3_tile<1, 1, 0>(L.tile_h, p, grid, nullptr);
+                if (k == 3) le = launch_h3_tile<3, 1, 0>(L.tile_h, p, grid, nullptr);
+                if (k == 5) le = launch_h3_tile<5, 1, 0>(L.tile_h, p, grid, nullptr);
+                if (k == 7) le = launch_h3_tile<7, 1, 0>(L.tile_h, p, grid, nullptr);
+            } else {
+                if (k == 1) le = launch_h3_tile<1, 2, 0>(L.tile_h, p, grid, nullptr);
+                if (k == 3) le = launch_h3_tile<3, 2, 0>(L.tile_h, p, grid, nullptr);
+                if (k == 5) le = launch_h3_tile<5, 2, 0>(L.tile_h, p, grid, nullptr);
+                if (k == 7) le = launch_h3_tile<7, 2, 0>(L.tile_h, p, grid, nullptr);
+            }
+            chk(le);
+        } else {
+            ConvParams p{};
+            p.x = static_cast<const float*>(dx); p.w = static_cast<const float*>(dw);
+            p.bias = static_cast<const float*>(db); p.y = static_cast<float*>(dy);
+            p.zeros = static_cast<const float*>(dz);
+            p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.cin_log2 = cl; p.x_ld = Cin; p.y_ld = Cout;
+            p.Cout = Cout; p.pad_t = pt; p.pad_l = pl; p.rate = rate; p.M = N * Ho * Wo;
+            p.nchunks = L.nchunks; p.Kpad = L.kpad; p.ntaps = k * k; p.ntiles_n = L.npad / L.BN; p.relu = relu;
+            dim3 grid((p.M + BM - 1) / BM * p.ntiles_n, 1);
+            chk(launch_conv(k, stride, L.BN, p, grid, nullptr));
+        }
         chk(hipDeviceSynchronize());
         chk(hipMemcpy(y, dy, ny * 4, hipMemcpyDeviceToHost));
     }

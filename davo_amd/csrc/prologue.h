@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
         fl[0] = f0.x; fl[1] = f0.y; fl[2] = f0.z; fl[3] = f0.w;
         fl[4] = f1.x; fl[5] = f1.y; fl[6] = f1.z; fl[7] = f1.w;
     }
-    float* o = out + (((size_t)(b * 2 + s) * H + y) * W + x) * LD;
+    constexpr int OUT_FLOATS = LD == 16 ? 8 : LD;          // LD 16 = split-fp16 layout, 8 floats' worth per pixel
+    float* o = out + (((size_t)(b * 2 + s) * H + y) * W + x) * OUT_FLOATS;
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
         const float mt = v.mask_rgb ? at[px] : 1.f, ms = v.mask_rgb ? as[px] : 1.f;
@@ -175,7 +176,20 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
         }
         r[6] = v.mask_info ? fl[2 * px] * mi : fl[2 * px];
         r[7] = v.mask_info ? fl[2 * px + 1] * mi : fl[2 * px + 1];
-        if (LD == 8) {
+        if (LD == 16) {
+            // split-fp16 form for the f16x3 convolutions: per pixel [8 hi halves | 8 lo halves]
+            // (32 bytes, the same as 8 floats): x = hi + lo * 2^-11
+            _Float16 hl[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const _Float16 h = (_Float16)r[k];
+                hl[k] = h;
+                hl[8 + k] = (_Float16)((r[k] - (float)h) * 2048.0f);
+            }
+            float4* o16 = reinterpret_cast<float4*>(o + px * 8);
+            o16[0] = *reinterpret_cast<const float4*>(&hl[0]);
+            o16[1] = *reinterpret_cast<const float4*>(&hl[8]);
+        } else if (LD == 8) {
             *reinterpret_cast<float4*>(o + px * 8) = make_float4(r[0], r[1], r[2], r[3]);
             *reinterpret_cast<float4*>(o + px * 8 + 4) = make_float4(r[4], r[5], r[6], r[7]);
         } else {

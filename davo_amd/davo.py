@@ -118,6 +118,10 @@ class Engine:
     def set_impl(self, impl):
         self._check(self._L.davo_set_impl(self._ctx, {"mfma": 0, "direct": 1}.get(impl, impl)))
 
+    def set_precision(self, precision):
+        """'f16x3' (default: split-fp16 MFMA, float32-grade) or 'f32' (FP32 MFMA, bit-exact fmaf chains)."""
+        self._check(self._L.davo_set_precision(self._ctx, {"f32": 0, "f16x3": 1}.get(precision, precision)))
+
     def profile(self, on):
         self._check(self._L.davo_profile_enable(self._ctx, int(on)))
 
@@ -149,7 +153,7 @@ class Engine:
         return out
 
 
-def conv2d_same(x, w, b, stride=1, rate=1, relu=True, device=0):
+def conv2d_same(x, w, b, stride=1, rate=1, relu=True, device=0, precision="f32"):
     """slim.conv2d(padding='SAME') through the MFMA implicit-GEMM kernel (test hook)."""
     x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32)
     b = np.ascontiguousarray(b, np.float32)
@@ -161,7 +165,8 @@ def conv2d_same(x, w, b, stride=1, rate=1, relu=True, device=0):
     err = ctypes.create_string_buffer(256)
     fp = ctypes.POINTER(ctypes.c_float)
     rc = _lib.lib().davo_conv2d_same(device, x.ctypes.data_as(fp), N, H, W, Cin, w.ctypes.data_as(fp), k, Cout,
-                                     b.ctypes.data_as(fp), stride, rate, int(relu), y.ctypes.data_as(fp), err, 256)
+                                     b.ctypes.data_as(fp), stride, rate, int(relu),
+                                     {"f32": 0, "f16x3": 1}[precision], y.ctypes.data_as(fp), err, 256)
     if rc != 0:
         raise _PY_ERR.get(rc, DavoError)(err.value.decode())
     return y

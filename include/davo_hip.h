@@ -106,6 +106,14 @@ int davo_profile_entry(davo_ctx* ctx, int i, char* name, int name_len, int* laun
  * price the FLOPs of the launch it puts on the roofline. */
 int davo_last_plan(davo_ctx* ctx, int layer, int launch, int* mtiles, int* bn);
 
+/* Arithmetic of the convolution stack:
+ *   1 (default) "f16x3": every float32 operand is split into two fp16 halves (22 significant
+ *      bits) and each product is three fp16 MFMA products accumulated in float32 — float32-grade
+ *      results (measured ~1e-7 relative on the 6-DoF outputs) at 5.3x less matrix-pipe time;
+ *      activations must stay within the fp16 range (|x| <= 65504, clamped).
+ *   0 "f32": v_mfma_f32_32x32x2_f32, bit-for-bit float32 fmaf chains, no range restriction. */
+int davo_set_precision(davo_ctx* ctx, int precision);
+
 /* ---- test hooks -------------------------------------------------------------------------
  * impl 0 = MFMA implicit-GEMM kernels (default, the product path);
  * impl 1 = one-thread-per-output direct convolution in HIP on the reference's own tensor
@@ -118,11 +126,12 @@ int davo_set_impl(davo_ctx* ctx, int impl);
 int davo_debug_read(davo_ctx* ctx, const char* tensor, float* host_out, size_t n_floats);
 
 /* Stand-alone slim.conv2d(padding='SAME') (nets/posenn.py:205-215) through the same MFMA
- * kernel, host pointers: x [N,H,W,Cin] (Cin a power of two >= 4), w HWIO [k,k,Cin,Cout],
- * y [N,ceil(H/stride),ceil(W/stride),Cout].  k in {1,3,5,7}, stride in {1,2}. */
+ * kernels, host pointers: x [N,H,W,Cin] float32 (Cin a power of two >= 4; >= 8 for f16x3),
+ * w HWIO [k,k,Cin,Cout], y [N,ceil(H/stride),ceil(W/stride),Cout] float32.
+ * k in {1,3,5,7}, stride in {1,2}; precision as davo_set_precision. */
 int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin,
                      const float* w, int k, int Cout, const float* bias,
-                     int stride, int rate, int relu, float* y, char* err, int err_len);
+                     int stride, int rate, int relu, int precision, float* y, char* err, int err_len);
 
 #ifdef __cplusplus
 }

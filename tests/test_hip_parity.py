@@ -25,49 +25,57 @@ pytestmark = pytest.mark.gpu
     (3, 1, 1, 4, 5, 1, 9, 11),          # ragged everything: M tail, K tail, N tail
     (3, 2, 3, 16, 40, 2, 21, 19),
 ])
-def test_conv_kernel_vs_oracle(k, stride, rate, cin, cout, N, H, W):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_conv_kernel_vs_oracle(k, stride, rate, cin, cout, N, H, W, precision):
+    if precision == "f16x3" and cin < 8:
+        pytest.skip("f16x3 k-chunks are built from 8-channel units")
     rng = np.random.RandomState(1000 * k + 100 * stride + 10 * rate + cin)
     x = rng.randn(N, H, W, cin).astype(np.float32)
     w = (rng.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
     b = (rng.randn(cout) * 0.1).astype(np.float32)
     for relu in (True, False):
         want = O.conv2d_same(x.astype(np.float64), w, b, stride, rate, relu)
-        got = conv2d_same(x, w, b, stride, rate, relu)
-        assert_layer_close(got, want, "conv k%d s%d r%d %d->%d relu=%s" % (k, stride, rate, cin, cout, relu), rtol=5e-6)
+        got = conv2d_same(x, w, b, stride, rate, relu, precision=precision)
+        assert_layer_close(got, want, "conv %s k%d s%d r%d %d->%d relu=%s" % (precision, k, stride, rate, cin, cout, relu), rtol=5e-6)
 
 
-def test_conv_kernel_asymmetric_operand():
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_conv_kernel_asymmetric_operand(precision):
     """A = identity-like input with an asymmetric kernel catches a transposed C/D map."""
     x = np.zeros((1, 8, 8, 32), np.float32)
     x[0, 3, 5, :] = np.arange(1, 33)
     w = np.zeros((1, 1, 32, 64), np.float32)
     for ci in range(32):
         w[0, 0, ci, (3 * ci + 1) % 64] = 1.0 + ci
-    got = conv2d_same(x, w, np.zeros(64, np.float32), 1, 1, False)
+    got = conv2d_same(x, w, np.zeros(64, np.float32), 1, 1, False, precision=precision)
     want = O.conv2d_same(x.astype(np.float64), w, np.zeros(64), 1, 1, False)
     assert np.array_equal(got, want.astype(np.float32))
 
 
 # ---- whole path, layer by layer ------------------------------------------------------------
-def _engine(cfg, H, W, B, weights):
+def _engine(cfg, H, W, B, weights, precision="f16x3"):
     e = Engine(cfg, H, W, B)
     e.load_weights(weights)
+    e.set_precision(precision)
     return e
+
+
+PRECISIONS = ["f16x3", "f32"]
 
 
 def _repack10_to_8(p10):
     return np.concatenate([p10[..., 0:3], p10[..., 5:10]], axis=-1)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "direct"])
-def test_layers_flagship_128x416(impl):
+@pytest.mark.parametrize("impl,precision", [("mfma", "f16x3"), ("mfma", "f32"), ("direct", "f32")])
+def test_layers_flagship_128x416(impl, precision):
     cfg = parse_version(FLAGSHIP_VERSION)
     B, H, W = 1, 128, 416
     img, flow, seg = synth.make_inputs(B, H, W)
     weights = synth.make_weights(cfg)
     keep = {}
     want = O.forward(cfg, img, flow, seg, weights, np.float64, keep)
-    e = _engine(cfg, H, W, B, weights)
+    e = _engine(cfg, H, W, B, weights, precision)
     e.set_impl(impl)
     got = e.forward(img, flow, seg)
     tab = e.debug_read("att_table", (B, 3, 19))
@@ -86,15 +94,16 @@ def test_layers_flagship_128x416(impl):
     c7 = e.debug_read("cnv7", (2 * B, 16, 52, 512))
     assert_layer_close(c7[..., :256], keep["rotation/cnv7"], "rot cnv7")
     assert_layer_close(c7[..., 256:], keep["translation/cnv7"], "trans cnv7")
-    assert_pose_close(got, want, "pose (%s)" % impl)
+    assert_pose_close(got, want, "pose (%s, %s)" % (impl, precision))
     e.close()
 
 
-def test_golden_cases_all_variants(c_oracle):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_golden_cases_all_variants(c_oracle, precision):
     g = load_golden()
     for name, case in g["cases"].items():
         cfg, img, flow, seg, weights = case_inputs(case)
-        e = _engine(cfg, case["H"], case["W"], case["B"], weights)
+        e = _engine(cfg, case["H"], case["W"], case["B"], weights, precision)
         got = e.forward(img, flow, seg)
         assert_pose_close(got, np.array(case["pose"]), name + " vs golden")
         if case["H"] * case["W"] <= 128 * 416:
@@ -102,12 +111,13 @@ def test_golden_cases_all_variants(c_oracle):
         e.close()
 
 
-def test_batching_is_per_sample_and_deterministic():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_batching_is_per_sample_and_deterministic(precision):
     """A window's pose must not depend on what else is in the batch or on max_batch."""
     cfg = parse_version(FLAGSHIP_VERSION)
     img, flow, seg = synth.make_inputs(5, 128, 416)
     weights = synth.make_weights(cfg)
-    e = _engine(cfg, 128, 416, 8, weights)
+    e = _engine(cfg, 128, 416, 8, weights, precision)
     all5 = e.forward(img, flow, seg)
     again = e.forward(img, flow, seg)
     assert np.array_equal(all5, again)                       # bitwise reproducible
@@ -116,6 +126,19 @@ def test_batching_is_per_sample_and_deterministic():
         assert np.array_equal(one[0], all5[i])
     rev = e.forward(img[::-1], flow[::-1], seg[::-1])
     assert np.array_equal(rev[::-1], all5)
+    e.close()
+
+
+def test_f16x3_close_to_f32_path():
+    """The two arithmetic modes agree far inside the parity bar (the split keeps 22 bits)."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(2, 128, 416)
+    w = synth.make_weights(cfg)
+    e = _engine(cfg, 128, 416, 2, w, "f32")
+    p32 = e.forward(img, flow, seg)
+    e.set_precision("f16x3")
+    p16 = e.forward(img, flow, seg)
+    assert np.abs(p16 - p32).max() <= 2e-6 * np.abs(p32).max()
     e.close()
 
 
