@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 MACS_PER_PAIR_128x416 = 3890085888
 CNV6_MACS_PER_PAIR_128x416 = 2 * 981467136          # rotation + translation cnv6, fused into one launch
 PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: FP32 matrix, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0                        # MI355X_MICROARCH.md: BF16/FP16 matrix, dense
 PEAK_HBM_GBS = 8000.0
 
 
@@ -50,6 +51,8 @@ def parse_args():
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=416)
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic windows generated per rank (tiled to the batch)")
+    ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
+                    help="f16x3: split-fp16 MFMA, float32-grade (default); f32: FP32 MFMA, bit-exact fmaf chains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="triplets per CPU-baseline pass")
     return ap.parse_args()
@@ -85,6 +88,7 @@ def main():
     weights = synth.make_weights(cfg)
     eng = Engine(cfg, H, W, B, device=local_rank)
     eng.load_weights(weights)
+    eng.set_precision(args.precision)
 
     # synthetic windows of this rank's shard, resident in HBM before the timed region
     nu = max(1, min(args.unique, B))
@@ -151,24 +155,34 @@ def main():
         achieved = cnv6_flops_main / (avg6 * 1e-3) / 1e12 if avg6 > 0 else 0.0
         kern_ms = {k: round(v[1] / max(v[0], 1), 4) for k, v in kernels.items()}
         whole = flops_per_triplet * B * args.steps / elapsed_max / 1e12
+        if args.precision == "f32":
+            peak, dtype = PEAK_F32_MFMA_TFLOPS, "f32"
+            kname = "davo::conv_igemm_f32<3,1,128,6> (cnv6 main launch: rotation|translation fused, N=256, K=2304)"
+            peak_note = "FP32 MFMA dense peak (v_mfma_f32_32x32x2_f32)"
+        else:
+            # every algorithmic FLOP costs three fp16 MFMA FLOPs (hi*hi, hi*lo, lo*hi), so the
+            # matrix-pipe roofline of this algorithm is the fp16 dense peak / 3
+            peak, dtype = PEAK_F16_MFMA_TFLOPS / 3.0, "f16x3 (fp16 hi/lo split operands, 3 MFMA products, f32 accumulate)"
+            kname = "davo::conv_igemm_h3<3,1,2,4,2,2,6> (cnv6: rotation|translation fused, N=256, K=2304, 128x256 tile)"
+            peak_note = "fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP; frac = matrix-pipe utilisation"
         res = {
             "metric": "pose-net triplets/sec (128x416x3-frame)" if (H, W) == (128, 416)
                       else "pose-net triplets/sec (%dx%dx3-frame)" % (H, W),
             "value": round(value, 2), "unit": "triplets/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic (splitmix64 seed 8964; random-init He-uniform weights; no KITTI/ckpt offline)",
             "config": {"workload": "BASELINE.json configs[1]: single MI355X, batch=%d synthetic %dx%d RGB+flow+seg "
                                    "triplets, dilatedPoseNN-cnv6_128 + se_flow + fc_tanh" % (B, H, W),
                        "version": FLAGSHIP_VERSION, "batch_per_gpu": B, "height": H, "width": W,
                        "parallelism": "window-sharded replicas x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "davo::conv_igemm_f32<3,1,128,6> (cnv6 main launch: rotation|translation fused, N=256, K=2304)",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None, "peak_note": peak_note,
                          "avg_launch_ms": round(avg6, 4), "flops_per_launch": cnv6_flops_main,
                          "launch_plan": "cnv6 as %s (mtiles of 128 rows, N tile)" % plan6},
             "whole_path_tflops_per_gpu": round(whole, 2),
-            "whole_path_frac_of_f32_mfma_peak": round(whole / PEAK_F32_MFMA_TFLOPS, 4),
+            "whole_path_frac_of_mfma_peak": round(whole / peak, 4),
             "kernel_avg_ms": kern_ms,
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
         }

@@ -158,13 +158,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         }                                                                                          \
     }
 
+    // The accumulators start at the bias (a lane's 16 results of a tile share one output channel),
+    // so the epilogue issues no load: a load there would make hipcc put `s_waitcnt vmcnt(0)` in
+    // front of every guarded store, and on gfx950 vmcnt counts stores too — the epilogue's stores
+    // would complete one by one.
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
-    for (int i = 0; i < T::TM; ++i)
+    for (int j = 0; j < T::TN; ++j) {
+        const float bv = bg[wn * T::TN * 32 + j * 32 + li];
 #pragma unroll
-        for (int j = 0; j < T::TN; ++j)
+        for (int i = 0; i < T::TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
 
     DAVO_LOAD_CHUNK(0)
     DAVO_STORE_CHUNK(0)
@@ -206,7 +212,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     for (int j = 0; j < T::TN; ++j) {
         const int ncol = wn * T::TN * 32 + j * 32 + li;          // column inside the N tile
         const int n = ntile * BN + ncol;
-        const float bv = bg[ncol];
         const bool n_ok = n < p.Cout;
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * T::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int m = mtile * BM + row;
-                float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r];
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (n_ok && m < p.M) yg[(long)m * p.y_ld + n] = v;
             }

@@ -63,7 +63,8 @@ template <int WM, int WN, int TM, int TN> struct TileH {
     static constexpr int A_LOADS = BMH * 8 / THREADS;
     static constexpr int B_LOADS = BNH * 8 / THREADS;
     static constexpr int ROWS_PER_PASS = THREADS / 8;
-    static constexpr int LDS_BYTES = 2 * (BMH + BNH) * LDB;
+    static constexpr int LDS_BYTES = 2 * (BMH + BNH) * LDB;          // register-staged: padded rows
+    static constexpr int LDS_BYTES_DMA = 2 * (BMH + BNH) * 128;      // LDS-DMA: linear rows, XOR-swizzled units
     static_assert(A_LOADS >= 1 && A_LOADS <= 4 && B_LOADS >= 1 && B_LOADS <= 4, "staging shape");
 };
 
@@ -71,14 +72,23 @@ __device__ __forceinline__ half8 lds_frag(const uint8_t* p) {
     return *reinterpret_cast<const half8*>(p);
 }
 
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN) > 4 ? 2 : 2)
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// DMA = false: global -> VGPR -> ds_write_b128 into rows padded to 144 B.
+// DMA = true : global_load_lds_dwordx4 straight into LDS (no staging registers, no ds_write pass).
+//   An LDS-DMA wave-instruction writes 1 KiB linearly (lane i -> base + 16 i = 8 rows of 128 B),
+//   so rows cannot be padded; bank conflicts are avoided by XOR-swizzling the 16-byte unit index
+//   with (row>>1)&7 — applied to the per-lane SOURCE address here and to the fragment reads.
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA>
+__global__ __launch_bounds__(WM * WN * 64, 2)
 void conv_igemm_h3(ConvParamsH p) {
     using T = TileH<WM, WN, TM, TN>;
     constexpr int BMH = T::BMH, BNH = T::BNH;
+    constexpr int ROWB = DMA ? 128 : LDB;              // LDS bytes per row
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_h[];
-    uint8_t* As = smem_h;                              // [2][BMH][LDB]
-    uint8_t* Bs = smem_h + 2 * BMH * LDB;              // [2][BNH][LDB]
+    uint8_t* As = smem_h;                              // [2][BMH][ROWB]
+    uint8_t* Bs = smem_h + 2 * BMH * ROWB;             // [2][BNH][ROWB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -94,7 +104,8 @@ void conv_igemm_h3(ConvParamsH p) {
 
     // ---- staging assignment: thread -> (row r0 + ROWS_PER_PASS*j, 16-byte unit u of the 128-byte row)
     // unit u: plane = u>>2 (0 = hi, 1 = lo), k-elements 8*(u&3) .. +7 of the chunk
-    const int r0 = tid >> 3, u = tid & 7;
+    const int r0 = tid >> 3;
+    const int u = DMA ? ((tid & 7) ^ ((r0 >> 1) & 7)) : (tid & 7);   // logical unit this thread fetches
     int iy0[T::A_LOADS], ix0[T::A_LOADS], pix0[T::A_LOADS];
 #pragma unroll
     for (int j = 0; j < T::A_LOADS; ++j) {
@@ -117,6 +128,7 @@ void conv_igemm_h3(ConvParamsH p) {
     const int tap_in_chunk = e0 >> p.cb_log2;                // which of the chunk's taps it belongs to
     const int unit_boff = (u >> 2) * (cb * 2) + (e0 & (cb - 1)) * 2;   // plane + channel offset in block
     const int ldsoff = r0 * LDB + u * 16;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wid);          // provably wave-uniform (LDS-DMA base -> M0)
 
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     ra1 = ra2 = ra3 = rb1 = rb2 = rb3 = make_uint4(0, 0, 0, 0);
@@ -156,21 +168,47 @@ void conv_igemm_h3(ConvParamsH p) {
         if constexpr (T::B_LOADS > 2) *reinterpret_cast<uint4*>(b_ + 2 * T::ROWS_PER_PASS * LDB) = rb2; \
         if constexpr (T::B_LOADS > 3) *reinterpret_cast<uint4*>(b_ + 3 * T::ROWS_PER_PASS * LDB) = rb3; \
     }
+#define H3_DMA_A(j_)                                                                               \
+    if constexpr (T::A_LOADS > j_) {                                                               \
+        const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
+        const bool ok = tap_ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win; \
+        const long off = (long)(pix0[j_] + iy * p.Win + ix) * p.x_pix_bytes + coff;                \
+        __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? xg + off : p.zeros),                       \
+                                         (lptr_t*)(a_ + (j_ * T::ROWS_PER_PASS + 8 * wave_u) * 128), 16, 0, 0); \
+    }
+#define H3_DMA_B(j_)                                                                               \
+    if constexpr (T::B_LOADS > j_)                                                                 \
+        __builtin_amdgcn_global_load_lds((gptr_t*)(wrow + (long)(T::ROWS_PER_PASS * j_) * p.w_row_bytes), \
+                                         (lptr_t*)(b_ + (j_ * T::ROWS_PER_PASS + 8 * wave_u) * 128), 16, 0, 0);
+#define H3_DMA_CHUNK(q_, buf_)                                                                     \
+    {                                                                                              \
+        const int cblk = (q_) / p.cpb, tq = (q_) - cblk * p.cpb;                                   \
+        const int tap = (tq << p.tpc_log2) + tap_in_chunk;                                         \
+        const int ky = tap / KS, kx = tap - ky * KS;                                               \
+        const int dy = ky * p.rate, dx = kx * p.rate;                                              \
+        const bool tap_ok = tap < p.ntaps;                                                         \
+        const int coff = cblk * (cb * 4) + unit_boff;                                              \
+        uint8_t* a_ = As + (buf_) * BMH * 128;                                                     \
+        uint8_t* b_ = Bs + (buf_) * BNH * 128;                                                     \
+        H3_DMA_A(0) H3_DMA_A(1) H3_DMA_A(2) H3_DMA_A(3)                                            \
+        const uint8_t* wrow = wg + (long)r0 * p.w_row_bytes + (long)(q_) * 128 + u * 16;           \
+        H3_DMA_B(0) H3_DMA_B(1) H3_DMA_B(2) H3_DMA_B(3)                                            \
+    }
     // one 32-k chunk = two K=16 MFMA steps; per step and output tile: hi*hi -> main,
     // hi*lo and lo*hi -> cross
 #define H3_COMPUTE(buf_)                                                                           \
     {                                                                                              \
-        const uint8_t* a = As + (buf_) * BMH * LDB + (wm * TM * 32 + li) * LDB + 16 * lh;          \
-        const uint8_t* b = Bs + (buf_) * BNH * LDB + (wn * TN * 32 + li) * LDB + 16 * lh;          \
+        const uint8_t* a = As + (buf_) * BMH * ROWB + (wm * TM * 32 + li) * ROWB;                  \
+        const uint8_t* b = Bs + (buf_) * BNH * ROWB + (wn * TN * 32 + li) * ROWB;                  \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                            \
             half8 ah[TM], al[TM], bh[TN], bl[TN];                                                  \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                       \
-                ah[i] = lds_frag(a + i * 32 * LDB + 32 * s);                                       \
-                al[i] = lds_frag(a + i * 32 * LDB + 64 + 32 * s);                                  \
+                ah[i] = lds_frag(a + i * 32 * ROWB + foff[0][s]);                                  \
+                al[i] = lds_frag(a + i * 32 * ROWB + foff[1][s]);                                  \
             }                                                                                      \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
-                bh[j] = lds_frag(b + j * 32 * LDB + 32 * s);                                       \
-                bl[j] = lds_frag(b + j * 32 * LDB + 64 + 32 * s);                                  \
+                bh[j] = lds_frag(b + j * 32 * ROWB + foff[0][s]);                                  \
+                bl[j] = lds_frag(b + j * 32 * ROWB + foff[1][s]);                                  \
             }                                                                                      \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
@@ -181,28 +219,53 @@ void conv_igemm_h3(ConvParamsH p) {
         }                                                                                          \
     }
 
+    // fragment byte offsets inside an LDS row for (plane, k-step): logical unit plane*4 + 2s + lh,
+    // XOR-swizzled with (row>>1)&7 = (li>>1)&7 in the DMA layout (tile row bases are multiples of 32)
+    int foff[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int unit = pl * 4 + 2 * s + lh;
+            foff[pl][s] = (DMA ? (unit ^ ((li >> 1) & 7)) : unit) * 16;
+        }
+
+    // main accumulators start at the bias so the epilogue issues no load (see conv_igemm.h)
     f32x16 accm[TM][TN], accx[TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+        const float bv = bg[wn * TN * 32 + j * 32 + li];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
-
-    H3_LOAD_CHUNK(0)
-    H3_STORE_CHUNK(0)
-    __syncthreads();
-
-    for (int q = 0; q + 1 < p.nchunks; ++q) {
-        const int buf = q & 1;
-        H3_LOAD_CHUNK(q + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        H3_COMPUTE(buf)
-        __builtin_amdgcn_sched_barrier(0);
-        H3_STORE_CHUNK(buf ^ 1)
-        __syncthreads();
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = bv; accx[i][j][r] = 0.f; }
     }
-    H3_COMPUTE((p.nchunks - 1) & 1)
+
+    if constexpr (DMA) {
+        H3_DMA_CHUNK(0, 0)
+        __syncthreads();                                  // hipcc drains the LDS-DMA (vmcnt(0)) here
+        for (int q = 0; q + 1 < p.nchunks; ++q) {
+            const int buf = q & 1;
+            H3_DMA_CHUNK(q + 1, buf ^ 1)                  // lands in the other buffer while we compute
+            H3_COMPUTE(buf)
+            __syncthreads();
+        }
+        H3_COMPUTE((p.nchunks - 1) & 1)
+    } else {
+        H3_LOAD_CHUNK(0)
+        H3_STORE_CHUNK(0)
+        __syncthreads();
+        for (int q = 0; q + 1 < p.nchunks; ++q) {
+            const int buf = q & 1;
+            H3_LOAD_CHUNK(q + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            H3_COMPUTE(buf)
+            __builtin_amdgcn_sched_barrier(0);
+            H3_STORE_CHUNK(buf ^ 1)
+            __syncthreads();
+        }
+        H3_COMPUTE((p.nchunks - 1) & 1)
+    }
 
     // ---- epilogue: combine, bias, ReLU; store float32 or re-split for the next layer ---------
     const int ocb_log2 = p.y_ld >= 32 ? 5 : (p.y_ld == 16 ? 4 : 3);
@@ -211,7 +274,6 @@ void conv_igemm_h3(ConvParamsH p) {
     for (int j = 0; j < TN; ++j) {
         const int ncol = wn * TN * 32 + j * 32 + li;
         const int n = ntile * BNH + ncol;
-        const float bv = bg[ncol];
         const bool n_ok = n < p.Cout;
         const int ng = p.y_coff + grp * p.g_y_coff + n;              // channel in the output tensor
         const long cbyte = (long)(ng >> ocb_log2) * (ocb * 4) + (ng & (ocb - 1)) * 2;
@@ -221,7 +283,7 @@ void conv_igemm_h3(ConvParamsH p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int m = mtile * BMH + row;
-                float v = accm[i][j][r] + accx[i][j][r] * (1.0f / 2048.0f) + bv;
+                float v = accm[i][j][r] + accx[i][j][r] * (1.0f / 2048.0f);
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (n_ok && m < p.M) {
                     if (p.y_mode == 0) {
@@ -240,6 +302,9 @@ void conv_igemm_h3(ConvParamsH p) {
 }
 
 #undef H3_LOAD_A
+#undef H3_DMA_A
+#undef H3_DMA_B
+#undef H3_DMA_CHUNK
 #undef H3_LOAD_B
 #undef H3_LOAD_CHUNK
 #undef H3_STORE_CHUNK

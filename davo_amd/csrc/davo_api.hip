@@ -253,19 +253,32 @@ TileShape tile_shape(int t) {
     }
 }
 
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER>
-hipError_t launch_h3_t(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+bool h3_use_dma() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DAVO_H3_DMA"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA>
+hipError_t launch_h3_d(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
     using T = TileH<WM, WN, TM, TN>;
-    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER>;
+    constexpr int lds = DMA ? T::LDS_BYTES_DMA : T::LDS_BYTES;
+    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, DMA>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(T::THREADS), T::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(T::THREADS), lds, s, p);
     return hipGetLastError();
+}
+
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER>
+hipError_t launch_h3_t(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    return h3_use_dma() ? launch_h3_d<KS, STRIDE, WM, WN, TM, TN, LAYER, true>(p, grid, s)
+                        : launch_h3_d<KS, STRIDE, WM, WN, TM, TN, LAYER, false>(p, grid, s);
 }
 
 template <int KS, int STRIDE, int LAYER>
