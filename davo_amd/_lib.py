@@ -7,7 +7,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdavo_hip.so")
+# DAVO_LIB_SUFFIX selects an experimental build (tools/build_variant.py); unset = the product library
+LIB_PATH = os.path.join(_HERE, "libdavo_hip%s.so" % os.environ.get("DAVO_LIB_SUFFIX", ""))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
@@ -37,7 +38,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
            "-Wno-unused-function", "-o", LIB_PATH, os.path.join(CSRC, "davo_api.hip"),
-           "-Wl,-rpath,/opt/rocm/lib"]
+           "-Wl,-rpath,/opt/rocm/lib"] + os.environ.get("DAVO_EXTRA_HIPCC_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

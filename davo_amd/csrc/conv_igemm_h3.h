@@ -4,17 +4,20 @@
 // FP32 MFMA runs at 1/16 of the fp16 rate on gfx950 and there is no xf32/TF32 path, so every
 // float32 operand is split into two fp16 numbers
 //
-//     a = ah + al * 2^-11,   ah = fp16(a),   al = fp16((a - ah) * 2^11)      (22 significant bits)
+//     a = ah + al,   ah = fp16(a),   al = fp16(a - ah)                     (22 significant bits)
 //
-// and a product is evaluated as three fp16 MFMA products accumulated in float32:
+// and a product is evaluated as three fp16 MFMA products accumulated in ONE float32 accumulator:
 //
-//     a*b  ~=  ah*bh + 2^-11 * (ah*bl + al*bh)                   (the dropped al*bl term is 2^-22)
+//     a*b  ~=  ah*bh + ah*bl + al*bh                              (the dropped al*bl term is 2^-22)
 //
-// ah*bh goes to one accumulator, the two cross terms to a second one that is scaled once in the
-// epilogue.  Each fp16 product is exact in float32 (11 x 11 bits), so the only loss is the 2^-22
-// representation error of the operands: measured end to end the 6-DoF outputs differ from the
-// float64 oracle by ~1e-7 relative, like the FP32-MFMA path, at 3 MFMA passes of 32 cycles per
-// K=16 instead of 8 passes of 64 cycles (5.3x less matrix-pipe time).
+// Each fp16 product is exact in float32 (11 x 11 bits), so the only loss is the representation
+// error of the operands.  The residual al is ~2^-11 |a| and may be an fp16 subnormal; that costs
+// absolute, not relative, accuracy (<= 2^-25 per operand), which is harmless for activations.
+// Weights are small (|w| ~ 0.05), so each layer's weights are pre-multiplied by a power of two
+// (max|w| -> [128,256), exact) before the split, which keeps their residuals normal, and the
+// epilogue multiplies the accumulator by the inverse power of two.  Measured end to end the 6-DoF
+// outputs differ from the float64 restatement by ~1e-7 relative, like the FP32-MFMA path, at
+// 3 MFMA passes of 32 cycles per K=16 instead of 8 passes of 64 cycles (5.3x less matrix-pipe time).
 //
 // Activations are STORED in the split form by the producing kernel's epilogue — 4 bytes per
 // element, the same HBM bytes as float32 — in a channel-blocked layout: per pixel, per block of
@@ -52,6 +55,8 @@ struct ConvParamsH {
     int M, ntaps, ntiles_n, mtile0, relu;
     int g_x_boff, g_y_coff;
     long g_w, g_bias;
+    float out_scale;        // 1 / (power of two the layer's weights were multiplied by)
+    int dbg;                // measurement only (DAVO_DBG): bit0 skip the loop's DMA, bit1 skip its MFMA phase
 };
 
 constexpr int LDB = 144;        // LDS row: 128 data bytes + 16 pad (conflict-free b128 fragment reads)
@@ -64,7 +69,11 @@ template <int WM, int WN, int TM, int TN> struct TileH {
     static constexpr int B_LOADS = BNH * 8 / THREADS;
     static constexpr int ROWS_PER_PASS = THREADS / 8;
     static constexpr int LDS_BYTES = 2 * (BMH + BNH) * LDB;          // register-staged: padded rows
-    static constexpr int LDS_BYTES_DMA = 2 * (BMH + BNH) * 128;      // LDS-DMA: linear rows, XOR-swizzled units
+#ifndef DAVO_H3_STAGES
+#define DAVO_H3_STAGES 2
+#endif
+    static constexpr int DMA_STAGES = DAVO_H3_STAGES;        // LDS ring slots (2 or 3)
+    static constexpr int LDS_BYTES_DMA = DMA_STAGES * (BMH + BNH) * 128;   // LDS-DMA ring: linear rows, XOR-swizzled units
     static_assert(A_LOADS >= 1 && A_LOADS <= 4 && B_LOADS >= 1 && B_LOADS <= 4, "staging shape");
 };
 
@@ -80,15 +89,19 @@ typedef __attribute__((address_space(3))) void lptr_t;
 //   An LDS-DMA wave-instruction writes 1 KiB linearly (lane i -> base + 16 i = 8 rows of 128 B),
 //   so rows cannot be padded; bank conflicts are avoided by XOR-swizzling the 16-byte unit index
 //   with (row>>1)&7 — applied to the per-lane SOURCE address here and to the fragment reads.
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA>
+// SMALLC: Cin < 32, a chunk spans several taps, so the tap (and its bounds test) differs per lane.
+// With Cin >= 32 the tap is uniform over the workgroup and everything about a chunk except the
+// image-bounds test is scalar: the loop then costs ~20 VALU instructions per 24 MFMAs.
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC>
 __global__ __launch_bounds__(WM * WN * 64, 2)
 void conv_igemm_h3(ConvParamsH p) {
     using T = TileH<WM, WN, TM, TN>;
     constexpr int BMH = T::BMH, BNH = T::BNH;
     constexpr int ROWB = DMA ? 128 : LDB;              // LDS bytes per row
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_h[];
-    uint8_t* As = smem_h;                              // [2][BMH][ROWB]
-    uint8_t* Bs = smem_h + 2 * BMH * ROWB;             // [2][BNH][ROWB]
+    constexpr int NSTAGE = DMA ? T::DMA_STAGES : 2;
+    uint8_t* As = smem_h;                              // [NSTAGE][BMH][ROWB]
+    uint8_t* Bs = smem_h + NSTAGE * BMH * ROWB;        // [NSTAGE][BNH][ROWB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -168,34 +181,46 @@ void conv_igemm_h3(ConvParamsH p) {
         if constexpr (T::B_LOADS > 2) *reinterpret_cast<uint4*>(b_ + 2 * T::ROWS_PER_PASS * LDB) = rb2; \
         if constexpr (T::B_LOADS > 3) *reinterpret_cast<uint4*>(b_ + 3 * T::ROWS_PER_PASS * LDB) = rb3; \
     }
+    // ---- LDS-DMA issue of one chunk ----------------------------------------------------------
+    // per-thread invariants: abase[j] = address of this thread's 16-byte unit at tap (0,0) of row j
+    // (a virtual address when that tap is padding: only dereferenced when in bounds);
+    // boff[j] = byte offset of its weight unit from the chunk's (uniform) weight base.
+    const uint8_t* abase[T::A_LOADS];
+    unsigned boff[T::B_LOADS];
+#pragma unroll
+    for (int j = 0; j < T::A_LOADS; ++j)
+        abase[j] = xg + ((long)pix0[j] + (long)iy0[j] * p.Win + ix0[j]) * p.x_pix_bytes + unit_boff;
+#pragma unroll
+    for (int j = 0; j < T::B_LOADS; ++j)
+        boff[j] = (unsigned)((r0 + T::ROWS_PER_PASS * j) * (int)p.w_row_bytes + u * 16);
 #define H3_DMA_A(j_)                                                                               \
     if constexpr (T::A_LOADS > j_) {                                                               \
         const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
         const bool ok = tap_ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win; \
-        const long off = (long)(pix0[j_] + iy * p.Win + ix) * p.x_pix_bytes + coff;                \
-        __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? xg + off : p.zeros),                       \
+        __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? abase[j_] + delta : p.zeros),              \
                                          (lptr_t*)(a_ + (j_ * T::ROWS_PER_PASS + 8 * wave_u) * 128), 16, 0, 0); \
     }
 #define H3_DMA_B(j_)                                                                               \
     if constexpr (T::B_LOADS > j_)                                                                 \
-        __builtin_amdgcn_global_load_lds((gptr_t*)(wrow + (long)(T::ROWS_PER_PASS * j_) * p.w_row_bytes), \
+        __builtin_amdgcn_global_load_lds((gptr_t*)(wq + boff[j_]),                                 \
                                          (lptr_t*)(b_ + (j_ * T::ROWS_PER_PASS + 8 * wave_u) * 128), 16, 0, 0);
+    // (cblk, tq) walk the chunks in order: scalar counters instead of a division per chunk
 #define H3_DMA_CHUNK(q_, buf_)                                                                     \
     {                                                                                              \
-        const int cblk = (q_) / p.cpb, tq = (q_) - cblk * p.cpb;                                   \
-        const int tap = (tq << p.tpc_log2) + tap_in_chunk;                                         \
+        const int tap = SMALLC ? (dma_tq << p.tpc_log2) + tap_in_chunk : dma_tq;                   \
         const int ky = tap / KS, kx = tap - ky * KS;                                               \
         const int dy = ky * p.rate, dx = kx * p.rate;                                              \
-        const bool tap_ok = tap < p.ntaps;                                                         \
-        const int coff = cblk * (cb * 4) + unit_boff;                                              \
+        const bool tap_ok = SMALLC ? tap < p.ntaps : true;                                         \
+        const long delta = ((long)dy * p.Win + dx) * p.x_pix_bytes + (long)dma_cblk * (cb * 4);    \
         uint8_t* a_ = As + (buf_) * BMH * 128;                                                     \
         uint8_t* b_ = Bs + (buf_) * BNH * 128;                                                     \
         H3_DMA_A(0) H3_DMA_A(1) H3_DMA_A(2) H3_DMA_A(3)                                            \
-        const uint8_t* wrow = wg + (long)r0 * p.w_row_bytes + (long)(q_) * 128 + u * 16;           \
+        const uint8_t* wq = wg + (long)(q_) * 128;                                                 \
         H3_DMA_B(0) H3_DMA_B(1) H3_DMA_B(2) H3_DMA_B(3)                                            \
+        if (++dma_tq == p.cpb) { dma_tq = 0; ++dma_cblk; }                                         \
     }
-    // one 32-k chunk = two K=16 MFMA steps; per step and output tile: hi*hi -> main,
-    // hi*lo and lo*hi -> cross
+    int dma_cblk = 0, dma_tq = 0;
+    // one 32-k chunk = two K=16 MFMA steps; per step and output tile: hi*hi, hi*lo, lo*hi
 #define H3_COMPUTE(buf_)                                                                           \
     {                                                                                              \
         const uint8_t* a = As + (buf_) * BMH * ROWB + (wm * TM * 32 + li) * ROWB;                  \
@@ -212,9 +237,9 @@ void conv_igemm_h3(ConvParamsH p) {
             }                                                                                      \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
-                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0); \
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0); \
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
                 }                                                                                  \
         }                                                                                          \
     }
@@ -230,27 +255,52 @@ void conv_igemm_h3(ConvParamsH p) {
             foff[pl][s] = (DMA ? (unit ^ ((li >> 1) & 7)) : unit) * 16;
         }
 
-    // main accumulators start at the bias so the epilogue issues no load (see conv_igemm.h)
-    f32x16 accm[TM][TN], accx[TM][TN];
+    // accumulators start at bias / out_scale (exact: out_scale is a power of two) so the epilogue
+    // issues no load (see conv_igemm.h)
+    f32x16 acc[TM][TN];
+    {
+        const float inv = 1.0f / p.out_scale;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const float bv = bg[wn * TN * 32 + j * 32 + li];
+        for (int j = 0; j < TN; ++j) {
+            const float bv = bg[wn * TN * 32 + j * 32 + li] * inv;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { accm[i][j][r] = bv; accx[i][j][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+        }
     }
 
     if constexpr (DMA) {
+        // LDS ring of NST slots, NST-1 chunks of LDS-DMA in flight.  The wait in front of each
+        // barrier is a COUNTED vmcnt (everything but this thread's newest NST-2 chunks), the barrier
+        // a raw s_barrier (__syncthreads() would always drain with vmcnt(0)), and a slot is read one
+        // iteration after the wait + barrier that retired it.  The slot refilled in iteration q was
+        // last read in iteration q-1, which every wave left through the previous barrier.
+        constexpr int NST = T::DMA_STAGES;
+        constexpr int NDMA = T::A_LOADS + T::B_LOADS;         // DMA instructions per thread per chunk
+        constexpr int KEEP = (NST - 2) * NDMA;                // instructions allowed to stay in flight
+        constexpr int WAIT_KEEP = (KEEP & 15) | (7 << 4) | (15 << 8) | ((KEEP >> 4) << 14);   // vmcnt(KEEP) only
+        constexpr int WAIT_ALL = (7 << 4) | (15 << 8);                                        // vmcnt(0) only
         H3_DMA_CHUNK(0, 0)
-        __syncthreads();                                  // hipcc drains the LDS-DMA (vmcnt(0)) here
-        for (int q = 0; q + 1 < p.nchunks; ++q) {
-            const int buf = q & 1;
-            H3_DMA_CHUNK(q + 1, buf ^ 1)                  // lands in the other buffer while we compute
-            H3_COMPUTE(buf)
-            __syncthreads();
+        if constexpr (NST == 3) {
+            if (p.nchunks > 1) H3_DMA_CHUNK(1, 1)
         }
-        H3_COMPUTE((p.nchunks - 1) & 1)
+        if (NST == 3 && p.nchunks > 1) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
+        else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;                                         // slot of chunk q
+        for (int q = 0; q < p.nchunks; ++q) {
+            const int nslot = slot == 0 ? NST - 1 : slot - 1; // (q + NST - 1) % NST
+            const bool more = q + NST - 1 < p.nchunks;
+            if (more && !(p.dbg & 1)) H3_DMA_CHUNK(q + NST - 1, nslot)
+            if (!(p.dbg & 2)) H3_COMPUTE(slot)
+            if (q + 1 < p.nchunks) {
+                if (NST == 3 && more) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
+                else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+                __builtin_amdgcn_s_barrier();
+            }
+            slot = slot == NST - 1 ? 0 : slot + 1;
+        }
     } else {
         H3_LOAD_CHUNK(0)
         H3_STORE_CHUNK(0)
@@ -283,7 +333,7 @@ void conv_igemm_h3(ConvParamsH p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int m = mtile * BMH + row;
-                float v = accm[i][j][r] + accx[i][j][r] * (1.0f / 2048.0f);
+                float v = acc[i][j][r] * p.out_scale;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (n_ok && m < p.M) {
                     if (p.y_mode == 0) {
@@ -291,7 +341,7 @@ void conv_igemm_h3(ConvParamsH p) {
                     } else {
                         v = fminf(fmaxf(v, -65504.f), 65504.f);     // fp16 range; see DESIGN.md
                         const _Float16 hi = (_Float16)v;
-                        const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+                        const _Float16 lo = (_Float16)(v - (float)hi);
                         uint8_t* o = p.y + (long)m * p.y_ld * 4 + cbyte;
                         *reinterpret_cast<_Float16*>(o) = hi;
                         *reinterpret_cast<_Float16*>(o + ocb * 2) = lo;

@@ -42,6 +42,7 @@ struct ConvLayer {
     float* d_b = nullptr;          // [groups][npad]
     // f16x3 path (conv_igemm_h3.h): channel-blocked k order, split-fp16 packed weights
     int cb_log2 = 0, tpc_log2 = 0, cpb = 0, nchunks_h = 0, npad_h = 0, tile_h = 0;
+    float wscale = 1.f;            // power of two the packed fp16 weights are multiplied by
     uint8_t* d_wh = nullptr;       // [groups][npad_h][nchunks_h][32 hi | 32 lo] halves
     float* d_bh = nullptr;         // [groups][npad_h]
 };
@@ -241,7 +242,7 @@ std::vector<Launch> plan_layer(int mtiles, int npad, int groups) {
 
 // ---- f16x3 path: tile shapes, weight packing, dispatch --------------------------------------
 // tile id -> (WM, WN, TM, TN): BM = WM*TM*32, BN = WN*TN*32, threads = WM*WN*64
-enum { TILE_128x32 = 0, TILE_256x64 = 1, TILE_256x128 = 2, TILE_128x256 = 3, TILE_128x128 = 4 };
+enum { TILE_128x32 = 0, TILE_256x64 = 1, TILE_256x128 = 2, TILE_128x256 = 3, TILE_128x128 = 4, TILE_256x256 = 5, NUM_TILES = 6 };
 struct TileShape { int bm, bn, threads, lds; };
 TileShape tile_shape(int t) {
     switch (t) {
@@ -249,7 +250,8 @@ TileShape tile_shape(int t) {
         case TILE_256x64: return {256, 64, 512, TileH<4, 2, 2, 1>::LDS_BYTES};
         case TILE_256x128: return {256, 128, 512, TileH<4, 2, 2, 2>::LDS_BYTES};
         case TILE_128x256: return {128, 256, 512, TileH<2, 4, 2, 2>::LDS_BYTES};
-        default: return {128, 128, 256, TileH<2, 2, 2, 2>::LDS_BYTES};
+        case TILE_256x256: return {256, 256, 512, TileH<4, 2, 2, 4>::LDS_BYTES};
+        default: return {128, 128, 512, TileH<4, 2, 1, 2>::LDS_BYTES};
     }
 }
 
@@ -259,12 +261,12 @@ bool h3_use_dma() {
     return v != 0;
 }
 
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA>
-hipError_t launch_h3_d(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC>
+hipError_t launch_h3_c(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
     using T = TileH<WM, WN, TM, TN>;
     constexpr int lds = DMA ? T::LDS_BYTES_DMA : T::LDS_BYTES;
-    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, DMA>;
+    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, DMA, SMALLC>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -273,6 +275,12 @@ hipError_t launch_h3_d(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(T::THREADS), lds, s, p);
     return hipGetLastError();
+}
+
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA>
+hipError_t launch_h3_d(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    return p.cb_log2 < 5 ? launch_h3_c<KS, STRIDE, WM, WN, TM, TN, LAYER, DMA, true>(p, grid, s)
+                         : launch_h3_c<KS, STRIDE, WM, WN, TM, TN, LAYER, DMA, false>(p, grid, s);
 }
 
 template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER>
@@ -288,7 +296,8 @@ hipError_t launch_h3_tile(int tile, const ConvParamsH& p, dim3 grid, hipStream_t
         case TILE_256x64: return launch_h3_t<KS, STRIDE, 4, 2, 2, 1, LAYER>(p, grid, s);
         case TILE_256x128: return launch_h3_t<KS, STRIDE, 4, 2, 2, 2, LAYER>(p, grid, s);
         case TILE_128x256: return launch_h3_t<KS, STRIDE, 2, 4, 2, 2, LAYER>(p, grid, s);
-        case TILE_128x128: return launch_h3_t<KS, STRIDE, 2, 2, 2, 2, LAYER>(p, grid, s);
+        case TILE_128x128: return launch_h3_t<KS, STRIDE, 4, 2, 1, 2, LAYER>(p, grid, s);
+        case TILE_256x256: return launch_h3_t<KS, STRIDE, 4, 2, 2, 4, LAYER>(p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -309,14 +318,24 @@ hipError_t launch_layer_h3(int layer, int tile, const ConvParamsH& p, dim3 grid,
 inline void split_f16(float v, _Float16* hi, _Float16* lo) {
     const _Float16 h = (_Float16)v;
     *hi = h;
-    *lo = (_Float16)((v - (float)h) * 2048.0f);
+    *lo = (_Float16)(v - (float)h);
+}
+
+// power of two that moves max|w| into [128, 256): keeps the fp16 residuals of small weights normal
+float weight_prescale(const float* w, size_t n) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i]));
+    if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
+    int e;
+    std::frexp(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+    return std::ldexp(1.0f, 8 - e);    // m * scale in [128, 256)
 }
 
 // HWIO float32 [KS,KS,Cin_tf,Cout] -> [npad][nchunks][32 hi | 32 lo] halves in the kernel's k
 // order: chunk q = (channel block cblk, tap group tq), element e -> tap = tq*tpc + e/CB,
 // channel = cblk*CB + e%CB.
 void pack_conv_weights_h3(const float* w_tf, int KS, int cin_tf, int cout, const int* chmap, int cin_packed,
-                          int cb_log2, int tpc_log2, int cpb, int nchunks, _Float16* out /*zeroed*/) {
+                          int cb_log2, int tpc_log2, int cpb, int nchunks, float scale, _Float16* out /*zeroed*/) {
     const int cb = 1 << cb_log2, ntaps = KS * KS;
     for (int q = 0; q < nchunks; ++q) {
         const int cblk = q / cpb, tq = q % cpb;
@@ -329,7 +348,7 @@ void pack_conv_weights_h3(const float* w_tf, int KS, int cin_tf, int cout, const
             const float* src = w_tf + ((size_t)tap * cin_tf + ci) * cout;
             for (int n = 0; n < cout; ++n) {
                 _Float16* o = out + ((size_t)n * nchunks + q) * 64;
-                split_f16(src[n], o + e, o + 32 + e);
+                split_f16(src[n] * scale, o + e, o + 32 + e);
             }
         }
     }
@@ -476,6 +495,10 @@ void init_layer(ConvLayer& L, const char* label, int KS, int stride, int rate, i
     L.cpb = (KS * KS + (32 / cb) - 1) / (32 / cb);
     L.nchunks_h = (cin / cb) * L.cpb;
     L.tile_h = cout <= 32 ? TILE_128x32 : cout <= 64 ? TILE_256x64 : cout <= 128 ? TILE_256x128 : TILE_128x256;
+    if (const char* e = getenv("DAVO_H3_TILE")) {          // measurement only: force a tile where it fits
+        const int t = atoi(e);
+        if (t >= 0 && t < NUM_TILES && cout >= tile_shape(t).bn) L.tile_h = t;
+    }
     const int bn = tile_shape(L.tile_h).bn;
     L.npad_h = (cout + bn - 1) / bn * bn;
 }
@@ -563,10 +586,24 @@ int build_packed_weights_h3(davo_ctx* c) {
         const size_t per_group = (size_t)L.npad_h * L.nchunks_h * 64;
         std::vector<_Float16> wp(per_group * L.groups, (_Float16)0.0f);
         std::vector<float> bp((size_t)L.npad_h * L.groups, 0.f);
+        {   // one power-of-two scale per layer (both heads share the launch)
+            float sc = 1e30f;
+            if (li < 5) {
+                const char* names[5] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5"};
+                const HostTensor& t = W(std::string("pose_exp_net/") + names[li] + "/weights");
+                sc = weight_prescale(t.data.data(), t.data.size());
+            } else {
+                for (int h = 0; h < 2; ++h) {
+                    const HostTensor& t = W(std::string("pose_exp_net/pose/") + heads[h] + (li == 5 ? "/cnv6/weights" : "/cnv7/weights"));
+                    sc = std::fmin(sc, weight_prescale(t.data.data(), t.data.size()));
+                }
+            }
+            L.wscale = sc;
+        }
         auto pack = [&](const std::string& wname, const std::string& bname, int cin_tf, int cout, const int* chmap,
                         _Float16* wdst, float* bdst) {
             pack_conv_weights_h3(W(wname).data.data(), L.KS, cin_tf, cout, chmap, L.cin, L.cb_log2, L.tpc_log2, L.cpb,
-                                 L.nchunks_h, wdst);
+                                 L.nchunks_h, L.wscale, wdst);
             memcpy(bdst, W(bname).data.data(), cout * sizeof(float));
         };
         if (li < 5) {
@@ -654,10 +691,12 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
     p.y_mode = y_f32 ? 0 : 1; p.y_ld = y_ld; p.y_coff = 0; p.Cout = L.cout;
     p.pad_t = pt; p.pad_l = pl; p.rate = L.rate;
     p.M = NB * Ho * Wo; p.ntaps = L.KS * L.KS; p.ntiles_n = L.npad_h / ts.bn; p.mtile0 = 0; p.relu = 1;
+    p.out_scale = 1.0f / L.wscale;
     if (L.groups == 2) {
         p.g_x_boff = L.cin * 4; p.g_y_coff = L.cout;
         p.g_w = (long)L.npad_h * p.w_row_bytes; p.g_bias = L.npad_h;
     }
+    if (const char* e = getenv("DAVO_DBG")) p.dbg = atoi(e);
     const int mtiles = (p.M + ts.bm - 1) / ts.bm;
     dim3 grid(mtiles * p.ntiles_n, L.groups);
     c->last_plan[li][0] = mtiles * 1000 + ts.bn; c->last_plan[li][1] = 0;
@@ -1049,7 +1088,7 @@ int davo_debug_read(davo_ctx* c, const char* tensor, float* host_out, size_t n_f
             const _Float16* raw = reinterpret_cast<const _Float16*>(host_out + px * ch);
             for (int k = 0; k < ch; ++k) {
                 const _Float16* blk = raw + (size_t)(k / cb) * cb * 2;
-                tmp[k] = (float)blk[k % cb] + (float)blk[cb + k % cb] * (1.0f / 2048.0f);
+                tmp[k] = (float)blk[k % cb] + (float)blk[cb + k % cb];
             }
             memcpy(host_out + px * ch, tmp.data(), ch * sizeof(float));
         }
@@ -1084,7 +1123,8 @@ int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, c
     size_t wbytes = 0;
     if (precision == 1) {
         wph.assign((size_t)L.npad_h * L.nchunks_h * 64, (_Float16)0.0f);
-        pack_conv_weights_h3(w, k, Cin, Cout, nullptr, Cin, L.cb_log2, L.tpc_log2, L.cpb, L.nchunks_h, wph.data());
+        L.wscale = weight_prescale(w, (size_t)k * k * Cin * Cout);
+        pack_conv_weights_h3(w, k, Cin, Cout, nullptr, Cin, L.cb_log2, L.tpc_log2, L.cpb, L.nchunks_h, L.wscale, wph.data());
         hw = wph.data(); wbytes = wph.size() * sizeof(_Float16);
         const int cb = 1 << L.cb_log2;                       // float32 NHWC -> split-fp16 blocked
         xh.resize(nx * 2);
@@ -1120,7 +1160,7 @@ int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, c
             p.cb_log2 = L.cb_log2; p.tpc_log2 = L.tpc_log2; p.cpb = L.cpb; p.nchunks = L.nchunks_h;
             p.w_row_bytes = (long)L.nchunks_h * 128; p.y_mode = 0; p.y_ld = Cout; p.Cout = Cout;
             p.pad_t = pt; p.pad_l = pl; p.rate = rate; p.M = N * Ho * Wo; p.ntaps = k * k;
-            p.ntiles_n = L.npad_h / ts.bn; p.relu = relu;
+            p.ntiles_n = L.npad_h / ts.bn; p.relu = relu; p.out_scale = 1.0f / L.wscale;
             dim3 grid((p.M + ts.bm - 1) / ts.bm * p.ntiles_n, 1);
             hipError_t le = hipErrorInvalidValue;
             if (stride == 1) {

@@ -178,13 +178,13 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
         r[7] = v.mask_info ? fl[2 * px + 1] * mi : fl[2 * px + 1];
         if (LD == 16) {
             // split-fp16 form for the f16x3 convolutions: per pixel [8 hi halves | 8 lo halves]
-            // (32 bytes, the same as 8 floats): x = hi + lo * 2^-11
+            // (32 bytes, the same as 8 floats): x = hi + lo
             _Float16 hl[16];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const _Float16 h = (_Float16)r[k];
                 hl[k] = h;
-                hl[8 + k] = (_Float16)((r[k] - (float)h) * 2048.0f);
+                hl[8 + k] = (_Float16)(r[k] - (float)h);
             }
             float4* o16 = reinterpret_cast<float4*>(o + px * 8);
             o16[0] = *reinterpret_cast<const float4*>(&hl[0]);
