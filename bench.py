@@ -147,7 +147,7 @@ def main():
         value = world * B * args.steps / elapsed_max
         # the dominant kernel = the main cnv6 launch (whole rounds of 128x128 tiles); a remainder
         # launch with narrower tiles, if the planner issued one, is listed as "cnv6.rem"
-        plan6 = eng.last_plan(5)
+        plan6 = eng.last_plan(5)                      # [(128-row M tiles, N tile | f16x3 tile id), ...]
         total_mtiles6 = sum(m for m, _ in plan6)
         cnv6_flops_main = cnv6_flops_per_launch * plan6[0][0] / total_mtiles6
         n6, ms6 = kernels.get("cnv6", (0, 0.0))

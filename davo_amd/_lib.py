@@ -26,7 +26,7 @@ class DavoVariant(ctypes.Structure):
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in ("davo_api.hip", "conv_igemm.h", "conv_igemm_h3.h", "prologue.h")] + \
+    return [os.path.join(CSRC, f) for f in ("davo_api.hip", "conv_igemm.h", "conv_igemm_h3.h", "conv_patch_h3.h", "prologue.h")] + \
            [os.path.join(INCLUDE, "davo_hip.h")]
 
 

@@ -93,7 +93,7 @@ typedef __attribute__((address_space(3))) void lptr_t;
 // With Cin >= 32 the tap is uniform over the workgroup and everything about a chunk except the
 // image-bounds test is scalar: the loop then costs ~20 VALU instructions per 24 MFMAs.
 template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC>
-__global__ __launch_bounds__(WM * WN * 64, 2)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 2)
 void conv_igemm_h3(ConvParamsH p) {
     using T = TileH<WM, WN, TM, TN>;
     constexpr int BMH = T::BMH, BNH = T::BNH;

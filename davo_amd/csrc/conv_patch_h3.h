@@ -1,0 +1,128 @@
+// conv_patch_h3.h — cnv1 (7x7, stride 2, 8 packed input channels -> 16) for the f16x3 path.
+//
+// As an implicit GEMM with a global-memory gather, cnv1 re-reads every input pixel ~12 times
+// (49 taps / stride^2): 1.4 GB of L2 traffic per 32-triplet batch for a 109 MB input, which made
+// it load-bound at 4x its matrix-pipe time.  Here a workgroup stages the input PATCH of its
+// 8 x 16 output tile (21 x 37 pixels, 25 KB) in LDS once by LDS-DMA and builds the MFMA A
+// fragments straight from the patch: the 8 channels of one tap of one pixel are exactly one
+// 16-byte fragment of v_mfma_f32_16x16x32_f16 (K = 32 = 4 taps x 8 channels, N = 16 = Cout, so
+// no padded output columns either).
+//
+// Patch layout: [plane hi|lo][py][column parity][px/2] x 16 B, rows padded to 32 units, so the
+// 16 lanes of a ds_read_b128 group (consecutive output columns, stride-2 input columns of one
+// parity) read 16 consecutive units = all 64 banks once; the two taps sharing a lane group differ
+// only by multiples of 256 B.  Taps are enumerated 8 per filter row (kx = 7 is a zero-weight
+// dummy) so the 4 taps of an MFMA step always lie in one filter row: 14 steps.
+//
+// Arithmetic is the same fp16 hi/lo split as conv_igemm_h3.h (3 MFMAs per step, one float32
+// accumulator, weights pre-scaled by a power of two).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_igemm_h3.h"
+
+namespace davo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace cp1 {
+constexpr int KS = 7, TH = 8, TW = 16;                 // filter, output tile
+constexpr int PH = 2 * TH + KS - 2, PW = 2 * TW + KS - 2;      // 21 x 37 input pixels
+constexpr int UNITS = 32;                              // 16-byte units per (py, parity) row (19 used)
+constexpr int ROWB = UNITS * 16;                       // 512 B
+constexpr int PLANE = PH * 2 * ROWB;                   // 21,504 B per plane (hi / lo)
+constexpr int STEPS = 2 * KS;                          // 14 MFMA steps (8 taps per filter row)
+constexpr int WBYTES = STEPS * 2 * 64 * 16;            // 28,672 B: [step][plane][lane] x 16 B
+constexpr int LDS_BYTES = 2 * PLANE + WBYTES;          // 71,680 B
+constexpr int THREADS = 256;
+}  // namespace cp1
+
+struct ConvPatchParams {
+    const uint8_t* x;       // packed split-fp16 input [NB][H][W][8 hi | 8 lo]
+    const uint8_t* w;       // [14][2][64][8] halves: B fragments in lane order, pre-scaled
+    const float* bias;      // [16]
+    uint8_t* y;             // split-fp16 blocked output [NB][Ho][Wo][16 hi | 16 lo]
+    const uint8_t* zeros;
+    int H, W, Ho, Wo, pad_t, pad_l;
+    int tiles_x, tiles_y;
+    float out_scale;
+};
+
+__global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchParams p) {
+    using namespace cp1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_p[];
+    uint8_t* patch = smem_p;                   // [2][PH][2][UNITS] x 16 B
+    uint8_t* wl = smem_p + 2 * PLANE;          // [STEPS][2][64] x 16 B
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y; const int n = b / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy_base = oy0 * 2 - p.pad_t, ix_base = ox0 * 2 - p.pad_l;
+
+    // ---- stage patch + weights by LDS-DMA: one wave-instruction = 64 units = 2 (py,parity) rows
+    const uint8_t* xin = p.x + (size_t)n * p.H * p.W * 32;
+    constexpr int PATCH_INSTR = PH;                            // per plane: one instruction = one py, both parities
+    for (int k = wave; k < 2 * PATCH_INSTR; k += 4) {
+        const int plane = k / PATCH_INSTR;
+        const int py = k - plane * PATCH_INSTR, par = lane >> 5, px2 = lane & 31;
+        const int iy = iy_base + py, ix = ix_base + 2 * px2 + par;
+        const bool ok = px2 * 2 + par < PW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const uint8_t* src = ok ? xin + ((size_t)iy * p.W + ix) * 32 + plane * 16 : p.zeros;
+        __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(patch + k * 1024), 16, 0, 0);
+    }
+    for (int k = wave; k < WBYTES / 1024; k += 4)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(p.w + (size_t)k * 1024 + lane * 16), (lptr_t*)(wl + k * 1024), 16, 0, 0);
+
+    // ---- accumulators: 2 subtiles per wave (output rows 2*wave, 2*wave+1), start at bias / out_scale
+    const int r = lane & 15, kq = lane >> 4;
+    const float bv = p.bias[r] * (1.0f / p.out_scale);         // C/D layout: col = lane & 15
+    f32x4 acc0 = {bv, bv, bv, bv}, acc1 = acc0;
+    // A fragment address of subtile row oy_l: py = 2*oy_l + ky, px = 2*r + 4*h + kq
+    const int a_lane = (kq & 1) * ROWB + (r + (kq >> 1)) * 16;
+    const uint8_t* a0 = patch + (2 * (2 * wave) * 2) * ROWB + a_lane;
+    const uint8_t* a1 = patch + (2 * (2 * wave + 1) * 2) * ROWB + a_lane;
+    const uint8_t* wb = wl + lane * 16;
+    __syncthreads();                                           // drains the LDS-DMA (vmcnt(0)) + barrier
+
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        const int ky = step >> 1, h = step & 1;
+        const int aoff = ky * 2 * ROWB + h * 32;               // filter row, +2 units for taps 4..7
+        const half8 bh = lds_frag(wb + (step * 2) * 1024);
+        const half8 bl = lds_frag(wb + (step * 2 + 1) * 1024);
+        const half8 ah0 = lds_frag(a0 + aoff), al0 = lds_frag(a0 + aoff + PLANE);
+        const half8 ah1 = lds_frag(a1 + aoff), al1 = lds_frag(a1 + aoff + PLANE);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, acc1, 0, 0, 0);
+    }
+
+    // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel), row = 4*(lane>>4) + i (pixel)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int oy = oy0 + 2 * wave + sub;
+        if (oy >= p.Ho) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ox = ox0 + 4 * kq + i;
+            float v = (sub == 0 ? acc0[i] : acc1[i]) * p.out_scale;
+            v = fminf(fmaxf(v, 0.f), 65504.f);
+            if (ox < p.Wo) {
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                uint8_t* o = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + r * 2;
+                *reinterpret_cast<_Float16*>(o) = hi;
+                *reinterpret_cast<_Float16*>(o + 32) = lo;
+            }
+        }
+    }
+}
+
+}  // namespace davo

@@ -21,6 +21,7 @@
 #include "../../include/davo_hip.h"
 #include "conv_igemm.h"
 #include "conv_igemm_h3.h"
+#include "conv_patch_h3.h"
 #include "prologue.h"
 
 using namespace davo;
@@ -85,10 +86,11 @@ struct davo_ctx {
     bool packed_ready = false;
     ConvLayer L[7];                            // cnv1..cnv5, cnv6 (fused), cnv7 (grouped)
     float *d_wpred = nullptr, *d_bpred = nullptr;
+    uint8_t* d_w1patch = nullptr;               // cnv1 B fragments for conv_patch_cnv1_h3
     // geometry
     int H1, W1, H2, W2, H3, W3;
     // workspace
-    float *d_partial = nullptr, *d_tab = nullptr, *d_packed = nullptr, *d_zeros = nullptr;
+    float *d_partial = nullptr, *d_tab = nullptr, *d_packed = nullptr, *d_zeros = nullptr, *d_pose_partial = nullptr;
     float* d_act[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t act_floats_per_img[7];
     int act_ch[7];
@@ -242,7 +244,7 @@ std::vector<Launch> plan_layer(int mtiles, int npad, int groups) {
 
 // ---- f16x3 path: tile shapes, weight packing, dispatch --------------------------------------
 // tile id -> (WM, WN, TM, TN): BM = WM*TM*32, BN = WN*TN*32, threads = WM*WN*64
-enum { TILE_128x32 = 0, TILE_256x64 = 1, TILE_256x128 = 2, TILE_128x256 = 3, TILE_128x128 = 4, TILE_256x256 = 5, NUM_TILES = 6 };
+enum { TILE_128x32 = 0, TILE_256x64 = 1, TILE_256x128 = 2, TILE_128x256 = 3, TILE_128x128 = 4, TILE_256x256 = 5, TILE_256x256_W16 = 6, NUM_TILES = 7 };
 struct TileShape { int bm, bn, threads, lds; };
 TileShape tile_shape(int t) {
     switch (t) {
@@ -251,6 +253,7 @@ TileShape tile_shape(int t) {
         case TILE_256x128: return {256, 128, 512, TileH<4, 2, 2, 2>::LDS_BYTES};
         case TILE_128x256: return {128, 256, 512, TileH<2, 4, 2, 2>::LDS_BYTES};
         case TILE_256x256: return {256, 256, 512, TileH<4, 2, 2, 4>::LDS_BYTES};
+        case TILE_256x256_W16: return {256, 256, 1024, TileH<4, 4, 2, 2>::LDS_BYTES};
         default: return {128, 128, 512, TileH<4, 2, 1, 2>::LDS_BYTES};
     }
 }
@@ -298,6 +301,7 @@ hipError_t launch_h3_tile(int tile, const ConvParamsH& p, dim3 grid, hipStream_t
         case TILE_128x256: return launch_h3_t<KS, STRIDE, 2, 4, 2, 2, LAYER>(p, grid, s);
         case TILE_128x128: return launch_h3_t<KS, STRIDE, 4, 2, 1, 2, LAYER>(p, grid, s);
         case TILE_256x256: return launch_h3_t<KS, STRIDE, 4, 2, 2, 4, LAYER>(p, grid, s);
+        case TILE_256x256_W16: return launch_h3_t<KS, STRIDE, 4, 4, 2, 2, LAYER>(p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -494,13 +498,13 @@ void init_layer(ConvLayer& L, const char* label, int KS, int stride, int rate, i
     L.tpc_log2 = ilog2_exact(32 / cb);
     L.cpb = (KS * KS + (32 / cb) - 1) / (32 / cb);
     L.nchunks_h = (cin / cb) * L.cpb;
-    L.tile_h = cout <= 32 ? TILE_128x32 : cout <= 64 ? TILE_256x64 : cout <= 128 ? TILE_256x128 : TILE_128x256;
-    if (const char* e = getenv("DAVO_H3_TILE")) {          // measurement only: force a tile where it fits
+    L.tile_h = -1;                                           // -1: the planner picks per launch
+    if (const char* e = getenv("DAVO_H3_TILE")) {            // measurement only: force a tile where it fits
         const int t = atoi(e);
         if (t >= 0 && t < NUM_TILES && cout >= tile_shape(t).bn) L.tile_h = t;
     }
-    const int bn = tile_shape(L.tile_h).bn;
-    L.npad_h = (cout + bn - 1) / bn * bn;
+    const int gran = cout > 128 ? 256 : cout > 64 ? 128 : cout > 32 ? 64 : 32;    // widest N tile a launch may use
+    L.npad_h = (cout + gran - 1) / gran * gran;
 }
 
 int build_packed_weights(davo_ctx* c) {
@@ -626,6 +630,25 @@ int build_packed_weights_h3(davo_ctx* c) {
         rc = upload(c, bp, &L.d_bh);
         if (rc) return rc;
     }
+    {   // cnv1 patch kernel: [14 steps][hi|lo][64 lanes][8 channels] halves, lane = (n = l&15, tap slot kq = l>>4)
+        const ConvLayer& L = c->L[0];
+        const HostTensor& t = W("pose_exp_net/cnv1/weights");
+        const int cin_tf = 2 * cpf;
+        std::vector<_Float16> wp((size_t)cp1::STEPS * 2 * 64 * 8, (_Float16)0.0f);
+        for (int step = 0; step < cp1::STEPS; ++step)
+            for (int l = 0; l < 64; ++l) {
+                const int n = l & 15, kq = l >> 4, ky = step >> 1, kx = 4 * (step & 1) + kq;
+                if (kx >= 7) continue;
+                for (int j = 0; j < 8; ++j) {
+                    const int ci = chmap1[j];
+                    if (ci < 0 || ci >= cin_tf) continue;
+                    const float v = t.data[(((size_t)ky * 7 + kx) * cin_tf + ci) * 16 + n] * L.wscale;
+                    split_f16(v, &wp[((size_t)(step * 2 + 0) * 64 + l) * 8 + j], &wp[((size_t)(step * 2 + 1) * 64 + l) * 8 + j]);
+                }
+            }
+        int rc = upload_bytes(c, wp.data(), wp.size() * sizeof(_Float16), reinterpret_cast<void**>(&c->d_w1patch));
+        if (rc) return rc;
+    }
     c->packed_h_ready = true;
     return DAVO_OK;
 }
@@ -673,6 +696,52 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
     return DAVO_OK;
 }
 
+// ---- f16x3 launch planning -------------------------------------------------------------------
+// Same idea as plan_layer: whole rounds of the most efficient tile, then a remainder launch with a
+// smaller tile that again fills whole rounds.  Costs are in units of one round of 256x256 tiles;
+// eff = measured throughput of the tile relative to 256x256 on the K >= 1152 layers.
+struct TileInfo { int id, per_cu; double eff; };
+const TileInfo kTiles[] = {{TILE_256x256, 1, 1.00}, {TILE_128x256, 1, 0.90}, {TILE_256x128, 1, 0.90},
+                           {TILE_128x128, 2, 0.75}, {TILE_256x64, 1, 0.70}, {TILE_128x32, 3, 0.40}};
+struct LaunchH { int row0, rows, tile; };
+
+double h3_cost(const TileInfo& t, long ntiles) {
+    const TileShape ts = tile_shape(t.id);
+    const long slots = 256L * t.per_cu;
+    return (double)((ntiles + slots - 1) / slots) * t.per_cu * (ts.bm * ts.bn / 65536.0) / t.eff;
+}
+
+std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile) {
+    auto ntiles = [&](const TileInfo& t, int rows) {
+        const TileShape ts = tile_shape(t.id);
+        return (long)((rows + ts.bm - 1) / ts.bm) * (npad / ts.bn) * groups;
+    };
+    auto fits = [&](const TileInfo& t) { const int bn = tile_shape(t.id).bn; return bn <= npad && npad % bn == 0; };
+    if (forced_tile >= 0) return {{0, M, forced_tile}};
+    std::vector<LaunchH> best;
+    double best_cost = 1e30;
+    for (const TileInfo& t1 : kTiles) {
+        if (!fits(t1)) continue;
+        const double c1 = h3_cost(t1, ntiles(t1, M));
+        if (c1 < best_cost - 1e-9) { best_cost = c1; best = {{0, M, t1.id}}; }
+        const TileShape s1 = tile_shape(t1.id);
+        const long per_round = 256L * t1.per_cu, per_m = (long)(npad / s1.bn) * groups;
+        if (per_round % per_m) continue;
+        const long m_per_round = per_round / per_m;                       // M tiles of t1 in one round
+        const long rounds = ((long)M / s1.bm) / m_per_round;
+        int rows1 = (int)(rounds * m_per_round * s1.bm);
+        rows1 -= rows1 % 256;                                             // every tile height divides 256
+        if (rows1 <= 0 || rows1 >= M) continue;
+        const double cm = h3_cost(t1, ntiles(t1, rows1));
+        for (const TileInfo& t2 : kTiles) {
+            if (!fits(t2)) continue;
+            const double c = cm + h3_cost(t2, ntiles(t2, M - rows1)) + 0.01;
+            if (c < best_cost - 1e-9) { best_cost = c; best = {{0, rows1, t1.id}, {rows1, M - rows1, t2.id}}; }
+        }
+    }
+    return best;
+}
+
 // f16x3 launch of conv layer li: x and y are split-fp16 blocked tensors (y float32 when y_f32)
 int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int Win, void* y, int y_ld,
                       bool y_f32, int NB) {
@@ -681,7 +750,6 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
     int Ho, Wo, pt, pl;
     same_pad(Hin, L.KS, L.stride, L.rate, &Ho, &pt);
     same_pad(Win, L.KS, L.stride, L.rate, &Wo, &pl);
-    const TileShape ts = tile_shape(L.tile_h);
     p.x = static_cast<const uint8_t*>(x); p.w = L.d_wh; p.bias = L.d_bh; p.y = static_cast<uint8_t*>(y);
     p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
     p.Hin = Hin; p.Win = Win; p.Hout = Ho; p.Wout = Wo;
@@ -690,18 +758,56 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
     p.w_row_bytes = (long)L.nchunks_h * 128;
     p.y_mode = y_f32 ? 0 : 1; p.y_ld = y_ld; p.y_coff = 0; p.Cout = L.cout;
     p.pad_t = pt; p.pad_l = pl; p.rate = L.rate;
-    p.M = NB * Ho * Wo; p.ntaps = L.KS * L.KS; p.ntiles_n = L.npad_h / ts.bn; p.mtile0 = 0; p.relu = 1;
+    p.M = NB * Ho * Wo; p.ntaps = L.KS * L.KS; p.mtile0 = 0; p.relu = 1;
     p.out_scale = 1.0f / L.wscale;
     if (L.groups == 2) {
         p.g_x_boff = L.cin * 4; p.g_y_coff = L.cout;
         p.g_w = (long)L.npad_h * p.w_row_bytes; p.g_bias = L.npad_h;
     }
     if (const char* e = getenv("DAVO_DBG")) p.dbg = atoi(e);
-    const int mtiles = (p.M + ts.bm - 1) / ts.bm;
-    dim3 grid(mtiles * p.ntiles_n, L.groups);
-    c->last_plan[li][0] = mtiles * 1000 + ts.bn; c->last_plan[li][1] = 0;
-    ProfScope ps(c, L.label);
-    HIP_TRY(c, launch_layer_h3(li, L.tile_h, p, grid, c->stream));
+    const std::vector<LaunchH> plan = plan_layer_h3(p.M, L.npad_h, L.groups, L.tile_h);
+    c->last_plan[li][0] = c->last_plan[li][1] = 0;
+    for (size_t i = 0; i < plan.size() && i < 2; ++i) {
+        const TileShape ts = tile_shape(plan[i].tile);
+        p.ntiles_n = L.npad_h / ts.bn;
+        p.mtile0 = plan[i].row0 / ts.bm;
+        const int full_m = p.M;
+        p.M = plan[i].row0 + plan[i].rows;                    // rows past this launch's range are not its job
+        const int mtiles = (plan[i].rows + ts.bm - 1) / ts.bm;
+        dim3 grid(mtiles * p.ntiles_n, L.groups);
+        c->last_plan[li][i] = ((plan[i].rows + 127) / 128) * 1000 + plan[i].tile;
+        const std::string label = i == 0 ? std::string(L.label) : std::string(L.label) + ".rem";
+        {
+            ProfScope ps(c, label.c_str());
+            HIP_TRY(c, launch_layer_h3(li, plan[i].tile, p, grid, c->stream));
+        }
+        p.M = full_m;
+    }
+    return DAVO_OK;
+}
+
+// cnv1 of the f16x3 path from an LDS-staged input patch (conv_patch_h3.h)
+int run_cnv1_patch(davo_ctx* c, const void* x, void* y, int NB) {
+    static bool attr_set = false;
+    const ConvLayer& L = c->L[0];
+    ConvPatchParams p{};
+    int Ho, Wo, pt, pl;
+    same_pad(c->H, 7, 2, 1, &Ho, &pt);
+    same_pad(c->W, 7, 2, 1, &Wo, &pl);
+    p.x = static_cast<const uint8_t*>(x); p.w = c->d_w1patch; p.bias = L.d_bh; p.y = static_cast<uint8_t*>(y);
+    p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
+    p.H = c->H; p.W = c->W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pt; p.pad_l = pl;
+    p.tiles_x = (Wo + cp1::TW - 1) / cp1::TW; p.tiles_y = (Ho + cp1::TH - 1) / cp1::TH;
+    p.out_scale = 1.0f / L.wscale;
+    if (!attr_set) {
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_cnv1_h3),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, cp1::LDS_BYTES));
+        attr_set = true;
+    }
+    c->last_plan[0][0] = ((NB * Ho * Wo + 127) / 128) * 1000 + 99; c->last_plan[0][1] = 0;
+    ProfScope ps(c, "cnv1");
+    hipLaunchKernelGGL(conv_patch_cnv1_h3, dim3(NB * p.tiles_x * p.tiles_y), dim3(cp1::THREADS), cp1::LDS_BYTES, c->stream, p);
+    HIP_TRY(c, hipGetLastError());
     return DAVO_OK;
 }
 
@@ -775,7 +881,9 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     float** a = c->d_act;
     int rc;
     if (h3) {
-        if ((rc = run_conv_layer_h3(c, 0, c->d_packed, 8, H, W, a[0], 16, false, NB))) return rc;
+        static const bool patch1 = !(getenv("DAVO_CNV1_PATCH") && atoi(getenv("DAVO_CNV1_PATCH")) == 0);
+        if (patch1) { if ((rc = run_cnv1_patch(c, c->d_packed, a[0], NB))) return rc; }
+        else if ((rc = run_conv_layer_h3(c, 0, c->d_packed, 8, H, W, a[0], 16, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 3, a[2], 64, c->H2, c->W2, a[3], 128, false, NB))) return rc;
@@ -808,8 +916,11 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     }
     {
         ProfScope ps(c, "pose_head");
-        hipLaunchKernelGGL(pose_head, dim3(NB, 2), dim3(256), 0, s, a[6], c->H3 * c->W3, c->d_wpred, c->d_bpred,
-                           static_cast<float*>(d_pose));
+        hipLaunchKernelGGL(pose_head_partial, dim3(PH_SPLIT, NB, 2), dim3(256), 0, s, a[6], c->H3 * c->W3, c->d_wpred,
+                           c->d_pose_partial);
+        HIP_TRY(c, hipGetLastError());
+        hipLaunchKernelGGL(pose_finish, dim3((NB * 6 + 63) / 64), dim3(64), 0, s, c->d_pose_partial, NB, c->H3 * c->W3,
+                           c->d_bpred, static_cast<float*>(d_pose));
         HIP_TRY(c, hipGetLastError());
     }
     c->last_B = B;
@@ -868,6 +979,7 @@ int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const d
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_packed), NB * (size_t)H * W * 10 * sizeof(float)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_partial), (size_t)max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_tab), (size_t)max_batch * 3 * NCLS * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_pose_partial), NB * 2 * PH_SPLIT * 3 * sizeof(float)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_zeros), 256));
     HIP_TRY(c, hipMemset(c->d_zeros, 0, 256));
     HIP_TRY(c, hipMemset(c->d_partial, 0, (size_t)max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
@@ -966,7 +1078,7 @@ void davo_destroy(davo_ctx* c) {
         if (L.d_bh) (void)hipFree(L.d_bh);
     }
     for (auto p : c->d_act) if (p) (void)hipFree(p);
-    void* misc[] = {c->d_zeros, c->d_wpred, c->d_bpred, c->d_partial, c->d_tab, c->d_packed, c->s_img, c->s_flow, c->s_seg, c->s_pose};
+    void* misc[] = {c->d_w1patch, c->d_pose_partial, c->d_zeros, c->d_wpred, c->d_bpred, c->d_partial, c->d_tab, c->d_packed, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
     for (auto& pe : c->prof_entries)
         for (auto& ab : pe.pending) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
@@ -1151,7 +1263,8 @@ int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, c
         chk(hipMemcpy(dw, hw, wbytes, hipMemcpyHostToDevice));
         chk(hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
         if (precision == 1) {
-            const TileShape ts = tile_shape(L.tile_h);
+            const int tile = Cout <= 32 ? TILE_128x32 : Cout <= 64 ? TILE_256x64 : Cout <= 128 ? TILE_256x128 : TILE_128x256;
+            const TileShape ts = tile_shape(tile);
             ConvParamsH p{};
             p.x = static_cast<const uint8_t*>(dx); p.w = static_cast<const uint8_t*>(dw);
             p.bias = static_cast<const float*>(db); p.y = static_cast<uint8_t*>(dy);
@@ -1164,15 +1277,15 @@ int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, c
             dim3 grid((p.M + ts.bm - 1) / ts.bm * p.ntiles_n, 1);
             hipError_t le = hipErrorInvalidValue;
             if (stride == 1) {
-                if (k == 1) le = launch_h3_tile<1, 1, 0>(L.tile_h, p, grid, nullptr);
-                if (k == 3) le = launch_h3_tile<3, 1, 0>(L.tile_h, p, grid, nullptr);
-                if (k == 5) le = launch_h3_tile<5, 1, 0>(L.tile_h, p, grid, nullptr);
-                if (k == 7) le = launch_h3_tile<7, 1, 0>(L.tile_h, p, grid, nullptr);
+                if (k == 1) le = launch_h3_tile<1, 1, 0>(tile, p, grid, nullptr);
+                if (k == 3) le = launch_h3_tile<3, 1, 0>(tile, p, grid, nullptr);
+                if (k == 5) le = launch_h3_tile<5, 1, 0>(tile, p, grid, nullptr);
+                if (k == 7) le = launch_h3_tile<7, 1, 0>(tile, p, grid, nullptr);
             } else {
-                if (k == 1) le = launch_h3_tile<1, 2, 0>(L.tile_h, p, grid, nullptr);
-                if (k == 3) le = launch_h3_tile<3, 2, 0>(L.tile_h, p, grid, nullptr);
-                if (k == 5) le = launch_h3_tile<5, 2, 0>(L.tile_h, p, grid, nullptr);
-                if (k == 7) le = launch_h3_tile<7, 2, 0>(L.tile_h, p, grid, nullptr);
+                if (k == 1) le = launch_h3_tile<1, 2, 0>(tile, p, grid, nullptr);
+                if (k == 3) le = launch_h3_tile<3, 2, 0>(tile, p, grid, nullptr);
+                if (k == 5) le = launch_h3_tile<5, 2, 0>(tile, p, grid, nullptr);
+                if (k == 7) le = launch_h3_tile<7, 2, 0>(tile, p, grid, nullptr);
             }
             chk(le);
         } else {

@@ -203,20 +203,25 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
 // Pose head tail: pred (1x1, 256 -> 3, linear) + mean over H3 x W3 + 0.01 scale
 // (nets/posenn.py:240-241,248-250).  pred and the mean are both linear, so
 //   pose[n][head*3+j] = 0.01 * ( b[j] + (1/P) * sum_c ( sum_p cnv7[n][p][head][c] ) * Wp[c][j] ).
-// grid (2B images, 2 heads), 256 threads = one per cnv7 channel (coalesced rows).
-__global__ __launch_bounds__(256) void pose_head(const float* __restrict__ c7, int P,
-                                                 const float* __restrict__ wpred /*[2][256][3]*/,
-                                                 const float* __restrict__ bpred /*[2][3]*/,
-                                                 float* __restrict__ pose /*[2B][6]*/) {
-    const int n = blockIdx.x, head = blockIdx.y, c = threadIdx.x;
+// Pass 1: grid (PH_SPLIT, 2B images, 2 heads), 256 threads = one per cnv7 channel (coalesced rows);
+// block s sums its slice of the P pixels and writes 3 partial dot products.  Pass 2 (pose_finish)
+// adds the PH_SPLIT partials in a fixed order -> bitwise reproducible.
+constexpr int PH_SPLIT = 8;
+
+__global__ __launch_bounds__(256) void pose_head_partial(const float* __restrict__ c7, int P,
+                                                         const float* __restrict__ wpred /*[2][256][3]*/,
+                                                         float* __restrict__ partial /*[2B][2][PH_SPLIT][3]*/) {
+    const int sp = blockIdx.x, n = blockIdx.y, head = blockIdx.z, c = threadIdx.x;
+    const int per = (P + PH_SPLIT - 1) / PH_SPLIT;
+    const int p0 = sp * per, p1 = min(p0 + per, P);
     const float* src = c7 + (size_t)n * P * 512 + head * 256 + c;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = 0;
-    for (; p + 4 <= P; p += 4) {
+    int p = p0;
+    for (; p + 4 <= p1; p += 4) {
         s0 += src[(size_t)p * 512]; s1 += src[(size_t)(p + 1) * 512];
         s2 += src[(size_t)(p + 2) * 512]; s3 += src[(size_t)(p + 3) * 512];
     }
-    for (; p < P; ++p) s0 += src[(size_t)p * 512];
+    for (; p < p1; ++p) s0 += src[(size_t)p * 512];
     const float sc = (s0 + s1) + (s2 + s3);
     const float* wp = wpred + ((size_t)head * 256 + c) * 3;
     float v[3] = {sc * wp[0], sc * wp[1], sc * wp[2]};
@@ -228,10 +233,21 @@ __global__ __launch_bounds__(256) void pose_head(const float* __restrict__ c7, i
         if (lane == 0) red[j][wid] = v[j];
     }
     __syncthreads();
-    if (c < 3) {
-        const float tot = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
-        pose[(size_t)n * 6 + head * 3 + c] = 0.01f * (tot / (float)P + bpred[head * 3 + c]);
-    }
+    if (c < 3)
+        partial[(((size_t)n * 2 + head) * PH_SPLIT + sp) * 3 + c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
+}
+
+__global__ __launch_bounds__(64) void pose_finish(const float* __restrict__ partial, int NB, int P,
+                                                  const float* __restrict__ bpred /*[2][3]*/,
+                                                  float* __restrict__ pose /*[2B][6]*/) {
+    const int i = blockIdx.x * 64 + threadIdx.x;           // (n, head, j)
+    if (i >= NB * 6) return;
+    const int n = i / 6, hj = i - n * 6, head = hj / 3, j = hj - head * 3;
+    const float* pp = partial + ((size_t)n * 2 + head) * PH_SPLIT * 3 + j;
+    float tot = 0.f;
+#pragma unroll
+    for (int s = 0; s < PH_SPLIT; ++s) tot += pp[s * 3];
+    pose[i] = 0.01f * (tot / (float)P + bpred[hj]);
 }
 
 // ---- on-device cross-check (impl 1): one thread per output element, reference layouts ----

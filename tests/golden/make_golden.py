@@ -25,6 +25,7 @@ CASES = [
     ("flagship_b2_128x416", FLAGSHIP_VERSION, 2, 128, 416, 1.0),
     ("flagship_b1_256x832", FLAGSHIP_VERSION, 1, 256, 832, 1.0),
     ("flagship_b3_32x64_smallflow", FLAGSHIP_VERSION, 3, 32, 64, 0.02),
+    ("flagship_b3_36x100_ragged", FLAGSHIP_VERSION, 3, 36, 100, 0.3),      # odd map sizes: every tile edge is ragged
     ("relu_normflow_absh_b2_64x96", "v1-sharedNN-dilatedPoseNN-segmask_all-se_flow-norm_flow-abs_flow_h", 2, 64, 96, 1.0),
     ("lrelu_segmask_rgb_b2_64x96", "v1-sharedNN-dilatedPoseNN-segmask_rgb-se_flow-fc_lrelu-abs_flow_v", 2, 64, 96, 0.05),
     ("no_segmask_b2_64x96", "v1-sharedNN-dilatedPoseNN-cnv6_64-no_segmask", 2, 64, 96, 1.0),
