@@ -101,6 +101,7 @@ struct davo_ctx {
     void *s_img = nullptr, *s_flow = nullptr, *s_seg = nullptr, *s_pose = nullptr;
     // profiling
     bool prof = false;
+    bool prof_dominant_only = false;           // profile mode 2: bracket only the main cnv6 launch
     std::vector<ProfEntry> prof_entries;
     std::vector<hipEvent_t> event_pool;
 };
@@ -381,6 +382,7 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     ProfScope(davo_ctx* ctx, const char* name) : c(ctx) {
         if (!c->prof) return;
+        if (c->prof_dominant_only && strcmp(name, "cnv6") != 0) return;
         for (auto& pe : c->prof_entries)
             if (pe.name == name) { e = &pe; break; }
         if (!e) {
@@ -1129,6 +1131,7 @@ int davo_profile_enable(davo_ctx* c, int on) {
     if (!c) return DAVO_ERR_INVALID;
     if (!on && c->prof) { int rc = prof_collect(c); if (rc) return rc; }
     c->prof = on != 0;
+    c->prof_dominant_only = on == 2;
     return DAVO_OK;
 }
 int davo_profile_reset(davo_ctx* c) {

@@ -123,6 +123,7 @@ class Engine:
         self._check(self._L.davo_set_precision(self._ctx, {"f32": 0, "f16x3": 1}.get(precision, precision)))
 
     def profile(self, on):
+        """0/False off, 1/True every kernel, 2 only the dominant kernel (main cnv6 launch)."""
         self._check(self._L.davo_profile_enable(self._ctx, int(on)))
 
     def profile_reset(self):

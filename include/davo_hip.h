@@ -95,7 +95,7 @@ int davo_set_stream(davo_ctx* ctx, void* hip_stream);
  * on the launch stream.  davo_profile_entry(i) returns the kernel's label, number of timed
  * launches and total device milliseconds since the last davo_profile_reset(); it returns
  * DAVO_ERR_INVALID once i is past the last entry.  Reading synchronises the stream. */
-int davo_profile_enable(davo_ctx* ctx, int on);
+int davo_profile_enable(davo_ctx* ctx, int on);   /* 0 off | 1 every kernel | 2 only the dominant kernel (main cnv6 launch) */
 int davo_profile_reset(davo_ctx* ctx);
 int davo_profile_entry(davo_ctx* ctx, int i, char* name, int name_len, int* launches,
                        double* total_ms);
