@@ -201,6 +201,22 @@ def main():
             kname = ("davo::conv_igemm_h3<3,1,...,6,true,false> (cnv6 main launch: rotation|translation fused, N=256, "
                      "K=2304, %s tile, LDS-DMA staged)" % tiles.get(plan6[0][1], "?"))
             peak_note = "fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP; frac = matrix-pipe utilisation"
+        # HBM traffic of the dominant kernel: from the most recent committed PMC pass (profiles/), not live —
+        # rocprofv3 counter collection cannot run inside the timed process
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+            key = "conv_igemm_f32<3, 1, 128, 6>" if args.precision == "f32" else "conv_igemm_h3<3, 1, 4, 2, 2, 4, 6, true, false>"
+            for f in reversed(cands):
+                tj = json.load(open(f))
+                hit = [v for k, v in tj["kernels"].items() if key in k]
+                if hit and (B, H, W) == (32, 128, 416):
+                    traffic = hit[0]["read_bytes"] + hit[0]["write_bytes"]
+                    traffic_src = "profiles/" + os.path.basename(f)
+                    break
+        except (OSError, ValueError, KeyError):
+            pass
         res = {
             "metric": "pose-net triplets/sec (128x416x3-frame)" if (H, W) == (128, 416)
                       else "pose-net triplets/sec (%dx%dx3-frame)" % (H, W),
@@ -214,7 +230,8 @@ def main():
                        "parallelism": "window-sharded replicas x%d" % world},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None, "peak_note": peak_note,
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                         "traffic_source": traffic_src, "peak_note": peak_note,
                          "avg_launch_ms": round(avg6, 4), "flops_per_launch": cnv6_flops_main,
                          "launch_plan": "cnv6 as %s (mtiles of 128 rows, N tile)" % plan6},
             "whole_path_tflops_per_gpu": round(whole, 2),

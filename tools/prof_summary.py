@@ -19,7 +19,7 @@ import shutil
 
 def find(d, pat):
     g = glob.glob(os.path.join(d, "**", pat), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None      # newest run if several were merged
 
 
 def short(name):
@@ -79,6 +79,14 @@ def main():
             lines.append("| `%s` | %.3g | %.3g | %.3f | %.3f | %.0f |" % (k, c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), gui, util, wait,
                                                                       c.get("SQ_LDS_BANK_CONFLICT", 0)))
         lines.append("")
+    if fe or wr:
+        import json
+        tr = {}
+        for k in sorted(set(fe) | set(wr)):
+            f = fe[k].get("FETCH_SIZE", []); w = wr[k].get("WRITE_SIZE", [])
+            tr[k] = {"read_bytes": 2 * (sum(f) / len(f) if f else 0.0) * 1024, "write_bytes": (sum(w) / len(w) if w else 0.0) * 1024}
+        json.dump({"source": os.path.basename(a.out), "note": "per launch; FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE exact",
+                   "kernels": tr}, open(a.out + "_traffic.json", "w"), indent=1)
     open(a.out + "_summary.md", "w").write("\n".join(lines))
     print("\n".join(lines))
 
