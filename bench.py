@@ -73,10 +73,27 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    # one rank per GPU; DAVO_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box) folds ranks onto the devices present
+    device_index = local_rank % ndev if os.environ.get("DAVO_BENCH_SHARE_GPU") == "1" else local_rank
+    if device_index >= ndev:
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
+    torch.cuda.set_device(device_index)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("DAVO_BENCH_BACKEND", "nccl")        # "nccl" is RCCL on ROCm
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", device_index))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        except Exception as e:                       # noqa: BLE001 — keep the measurement alive on gloo
+            sys.stderr.write("rank %d: %s init failed (%s); falling back to gloo\n" % (rank, backend, e))
+            backend = "gloo"
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm_dev = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
 
     from davo_amd import Engine, synth, parse_version, FLAGSHIP_VERSION
     cfg = parse_version(FLAGSHIP_VERSION)
@@ -86,7 +103,7 @@ def main():
     cnv6_flops_per_launch = 2 * CNV6_MACS_PER_PAIR_128x416 * scale_px * (2 * B)
 
     weights = synth.make_weights(cfg)
-    eng = Engine(cfg, H, W, B, device=local_rank)
+    eng = Engine(cfg, H, W, B, device=device_index)
     eng.load_weights(weights)
     eng.set_precision(args.precision)
 
@@ -159,23 +176,27 @@ def main():
         eng.forward_device(B, d_img, d_flow, d_seg, d_pose)      # d_pose holds the f16x3 result again
         eng.synchronize()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
 
     poses = d_pose.download((B, 2, 6))
 
-    # one RCCL gather of the shard poses (config 4's stitch input), outside the timed region
-    gather_ms = None
+    # one gather of the shard poses (config 4's stitch input) over RCCL, outside the timed region
+    gather_ms, gather_err = None, None
     if world > 1:
-        mine = torch.from_numpy(poses).cuda()
-        out = [torch.empty_like(mine) for _ in range(world)]
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        dist.all_gather(out, mine)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        try:
+            mine = torch.from_numpy(poses).to(comm_dev)
+            out = [torch.empty_like(mine) for _ in range(world)]
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            dist.all_gather(out, mine)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            assert torch.equal(out[rank].cpu(), torch.from_numpy(poses))
+        except Exception as e:                       # noqa: BLE001
+            gather_err = "%s: %s" % (type(e).__name__, e)
 
     if rank == 0:
         value = world * B * args.steps / elapsed_max
@@ -239,6 +260,7 @@ def main():
             "kernel_avg_ms": kern_ms,
             "f32_exact_mode": f32_mode,
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "gather_backend": backend, "gather_error": gather_err,
         }
         # parity on the bench's own batch (bounded: the first 2 windows) + CPU baseline beside it
         from oracle import c_oracle

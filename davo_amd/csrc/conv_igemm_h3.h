@@ -339,12 +339,19 @@ void conv_igemm_h3(ConvParamsH p) {
                     if (p.y_mode == 0) {
                         reinterpret_cast<float*>(p.y)[(long)m * p.y_ld + ng] = v;
                     } else {
+                        // split, then pair up with the neighbouring lane (= neighbouring channel) so that
+                        // every lane issues ONE 4-byte store instead of two 2-byte ones: even lanes store
+                        // the hi halves of channels (n, n+1), odd lanes the lo halves of (n-1, n)
                         v = fminf(fmaxf(v, -65504.f), 65504.f);     // fp16 range; see DESIGN.md
                         const _Float16 hi = (_Float16)v;
                         const _Float16 lo = (_Float16)(v - (float)hi);
-                        uint8_t* o = p.y + (long)m * p.y_ld * 4 + cbyte;
-                        *reinterpret_cast<_Float16*>(o) = hi;
-                        *reinterpret_cast<_Float16*>(o + ocb * 2) = lo;
+                        const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                           ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                        const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                        const bool odd = lane & 1;
+                        const unsigned word = odd ? ((xn >> 16) | (x & 0xffff0000u)) : ((x & 0xffffu) | (xn << 16));
+                        uint8_t* o = p.y + (long)m * p.y_ld * 4 + cbyte + (odd ? ocb * 2 - 2 : 0);
+                        *reinterpret_cast<unsigned*>(o) = word;
                     }
                 }
             }

@@ -115,11 +115,16 @@ __global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchP
             float v = (sub == 0 ? acc0[i] : acc1[i]) * p.out_scale;
             v = fminf(fmaxf(v, 0.f), 65504.f);
             if (ox < p.Wo) {
+                // even lanes store the hi halves of channels (n, n+1), odd lanes the lo halves of (n-1, n)
                 const _Float16 hi = (_Float16)v;
                 const _Float16 lo = (_Float16)(v - (float)hi);
-                uint8_t* o = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + r * 2;
-                *reinterpret_cast<_Float16*>(o) = hi;
-                *reinterpret_cast<_Float16*>(o + 32) = lo;
+                const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                   ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+                const bool odd = r & 1;
+                const unsigned word = odd ? ((xn >> 16) | (x & 0xffff0000u)) : ((x & 0xffffu) | (xn << 16));
+                uint8_t* o = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + (odd ? 32 + (r - 1) * 2 : r * 2);
+                *reinterpret_cast<unsigned*>(o) = word;
             }
         }
     }

@@ -735,8 +735,10 @@ std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile)
         rows1 -= rows1 % 256;                                             // every tile height divides 256
         if (rows1 <= 0 || rows1 >= M) continue;
         const double cm = h3_cost(t1, ntiles(t1, rows1));
+        static const int rem_force = getenv("DAVO_H3_REM_TILE") ? atoi(getenv("DAVO_H3_REM_TILE")) : -1;
         for (const TileInfo& t2 : kTiles) {
             if (!fits(t2)) continue;
+            if (rem_force >= 0 && t2.id != rem_force) continue;
             const double c = cm + h3_cost(t2, ntiles(t2, M - rows1)) + 0.01;
             if (c < best_cost - 1e-9) { best_cost = c; best = {{0, rows1, t1.id}, {rows1, M - rows1, t2.id}}; }
         }
