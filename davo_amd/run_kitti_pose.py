@@ -7,7 +7,9 @@ writes ``<seq>-pred_kitti_pose.txt``.
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
         -m davo_amd.run_kitti_pose ... --batch_size 64       # windows sharded over 8 GPUs
 
-``--ckpt_file`` is an ``.npz`` keyed by the TF variable names (SURVEY table W); with
+``--ckpt_file`` is a TF V2 checkpoint as the reference's Saver wrote it (prefix, ``.index`` file or the
+directory holding ``checkpoint``; davo_amd/tf_checkpoint.py reads it without TensorFlow) or an ``.npz``
+keyed by the TF variable names (SURVEY table W); with
 ``--synthetic N`` the inputs and weights are the seeded synthetic ones (no KITTI dump or
 checkpoint exists offline) and N is the frame count (801 = seq 03, 4541 = seq 00).
 """
@@ -58,7 +60,8 @@ def main(argv=None):
         d = os.path.join(a.concat_img_dir, "%.2d" % a.test_seq)
         n_frames = len(glob(d + "/*.jpg")) + 2 * int((a.seq_length - 1) / 2)      # test_kitti_pose.py:81-82
         load = S.kitti_window_loader(a.concat_img_dir, a.test_seq, n_frames, H, W)
-        weights = dict(np.load(a.ckpt_file))
+        from .tf_checkpoint import load_weights
+        weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
 
     system = DAVO(version=a.version, device=local_rank)
     system.load_weights(weights)
