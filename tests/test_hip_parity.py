@@ -236,3 +236,46 @@ def test_sequence_driver_on_gpu(tmp_path, c_oracle):
     want, _ = S.run_sequence(infer, S.synthetic_window_loader(64, 96), 13, 4)
     assert got.shape == (13, 4, 4)
     assert np.abs(got - np.array(want)).max() < 2e-4
+
+
+# ---- BASELINE.json configurations at full size ---------------------------------------------------
+def test_config2_batch32_full_size(c_oracle):
+    """configs[1]: B=32, 128x416 — every window against the C oracle (multi-launch plan, remainder tiles)."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B = 32
+    img, flow, seg = synth.make_inputs(B, 128, 416, first_window=100)
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, 128, 416, B, weights, "f16x3")
+    got = e.forward(img, flow, seg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    assert_pose_close(got, want, "B=32 f16x3")
+    e.set_precision("f32")
+    assert_pose_close(e.forward(img, flow, seg), want, "B=32 f32")
+    e.close()
+
+
+def test_config3_batch128_properties(c_oracle):
+    """configs[2]: B=128 — 16 distinct windows tiled 8x: duplicates must produce identical poses
+    wherever they sit in the batch (any tile, any launch of the plan), and a sample matches the oracle."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img16, flow16, seg16 = synth.make_inputs(16, 128, 416, first_window=500)
+    weights = synth.make_weights(cfg)
+    img, flow, seg = np.tile(img16, (8, 1, 1, 1)), np.tile(flow16, (8, 1, 1, 1, 1)), np.tile(seg16, (8, 1, 1, 1, 1))
+    e = _engine(cfg, 128, 416, 128, weights, "f16x3")
+    got = e.forward(img, flow, seg).reshape(8, 16, 2, 6)
+    for r in range(1, 8):
+        assert np.array_equal(got[r], got[0])
+    assert_pose_close(got[0, :4], c_oracle.forward(cfg, img16[:4], flow16[:4], seg16[:4], weights), "B=128 sample")
+    e.close()
+
+
+def test_config5_256x832(c_oracle):
+    """configs[4] shape: 256x832 inputs, a small batch against the oracle in both modes."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(2, 256, 832, first_window=7)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    for prec in PRECISIONS:
+        e = _engine(cfg, 256, 832, 2, weights, prec)
+        assert_pose_close(e.forward(img, flow, seg), want, "256x832 %s" % prec)
+        e.close()

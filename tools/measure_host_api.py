@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""PCIe-inclusive rate of the host-buffer entry point davo_forward: numpy arrays in
+pageable host memory -> poses on the host, B=32, 128x416.  Not the bench metric (bench.py keeps the
+inputs resident in HBM); reported for information."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np                                                   # noqa: E402
+from davo_amd import Engine, synth, parse_version, FLAGSHIP_VERSION   # noqa: E402
+
+B = 32
+cfg = parse_version(FLAGSHIP_VERSION)
+img, flow, seg = synth.make_inputs(8, 128, 416)
+img, flow, seg = np.tile(img, (4, 1, 1, 1)), np.tile(flow, (4, 1, 1, 1, 1)), np.tile(seg, (4, 1, 1, 1, 1))
+e = Engine(cfg, 128, 416, B)
+e.load_weights(synth.make_weights(cfg))
+for _ in range(3):
+    e.forward(img, flow, seg)
+t0 = time.perf_counter()
+n = 20
+for _ in range(n):
+    e.forward(img, flow, seg)
+dt = time.perf_counter() - t0
+mb = (img.nbytes + flow.nbytes + seg.nbytes) / 1e6
+print("davo_forward (host buffers, pageable): %.1f triplets/s, %.3f ms per batch of %d, %.1f MB in per batch -> %.1f GB/s H2D-equivalent"
+      % (B * n / dt, dt / n * 1e3, B, mb, mb * n / dt / 1e3))
