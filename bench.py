@@ -218,7 +218,7 @@ def main():
             # every algorithmic FLOP costs three fp16 MFMA FLOPs (hi*hi, hi*lo, lo*hi), so the
             # matrix-pipe roofline of this algorithm is the fp16 dense peak / 3
             peak, dtype = PEAK_F16_MFMA_TFLOPS / 3.0, "f16x3 (fp16 hi/lo split operands, 3 MFMA products, f32 accumulate)"
-            tiles = {0: "128x32", 1: "256x64", 2: "256x128", 3: "128x256", 4: "128x128", 5: "256x256", 6: "256x256/16 waves"}
+            tiles = {0: "128x32", 1: "256x64", 2: "256x128", 3: "128x256", 4: "128x128", 5: "256x256"}
             kname = ("davo::conv_igemm_h3<3,1,...,6,true,false> (cnv6 main launch: rotation|translation fused, N=256, "
                      "K=2304, %s tile, LDS-DMA staged)" % tiles.get(plan6[0][1], "?"))
             peak_note = "fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP; frac = matrix-pipe utilisation"

@@ -84,11 +84,11 @@ __device__ __forceinline__ half8 lds_frag(const uint8_t* p) {
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-// DMA = false: global -> VGPR -> ds_write_b128 into rows padded to 144 B.
-// DMA = true : global_load_lds_dwordx4 straight into LDS (no staging registers, no ds_write pass).
-//   An LDS-DMA wave-instruction writes 1 KiB linearly (lane i -> base + 16 i = 8 rows of 128 B),
-//   so rows cannot be padded; bank conflicts are avoided by XOR-swizzling the 16-byte unit index
-//   with (row>>1)&7 — applied to the per-lane SOURCE address here and to the fragment reads.
+// Staging is LDS-DMA only (DMA must be true): global_load_lds_dwordx4 straight into LDS, no staging
+// registers, no ds_write pass.  An LDS-DMA wave-instruction writes 1 KiB linearly (lane i -> base +
+// 16 i = 8 rows of 128 B), so rows cannot be padded; bank conflicts are avoided by XOR-swizzling the
+// 16-byte unit index with (row>>1)&7 — applied to the per-lane SOURCE address here and to the
+// fragment reads.  (A register-staged variant with rows padded to 144 B measured 10-15 % slower.)
 // SMALLC: Cin < 32, a chunk spans several taps, so the tap (and its bounds test) differs per lane.
 // With Cin >= 32 the tap is uniform over the workgroup and everything about a chunk except the
 // image-bounds test is scalar: the loop then costs ~20 VALU instructions per 24 MFMAs.
@@ -140,47 +140,8 @@ void conv_igemm_h3(ConvParamsH p) {
     const int e0 = (u & 3) * 8;                              // first k-element of this unit
     const int tap_in_chunk = e0 >> p.cb_log2;                // which of the chunk's taps it belongs to
     const int unit_boff = (u >> 2) * (cb * 2) + (e0 & (cb - 1)) * 2;   // plane + channel offset in block
-    const int ldsoff = r0 * LDB + u * 16;
     const int wave_u = __builtin_amdgcn_readfirstlane(wid);          // provably wave-uniform (LDS-DMA base -> M0)
 
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    ra1 = ra2 = ra3 = rb1 = rb2 = rb3 = make_uint4(0, 0, 0, 0);
-
-#define H3_LOAD_A(j_, dst_)                                                                        \
-    if constexpr (T::A_LOADS > j_) {                                                               \
-        const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
-        const bool ok = tap_ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win; \
-        const long off = (long)(pix0[j_] + iy * p.Win + ix) * p.x_pix_bytes + coff;                \
-        dst_ = *reinterpret_cast<const uint4*>(ok ? xg + off : p.zeros);                           \
-    }
-#define H3_LOAD_B(j_, dst_)                                                                        \
-    if constexpr (T::B_LOADS > j_)                                                                 \
-        dst_ = *reinterpret_cast<const uint4*>(wrow + (long)(T::ROWS_PER_PASS * j_) * p.w_row_bytes);
-#define H3_LOAD_CHUNK(q_)                                                                          \
-    {                                                                                              \
-        const int cblk = (q_) / p.cpb, tq = (q_) - cblk * p.cpb;                                   \
-        const int tap = (tq << p.tpc_log2) + tap_in_chunk;                                         \
-        const int ky = tap / KS, kx = tap - ky * KS;                                               \
-        const int dy = ky * p.rate, dx = kx * p.rate;                                              \
-        const bool tap_ok = tap < p.ntaps;                                                         \
-        const int coff = cblk * (cb * 4) + unit_boff;                                              \
-        H3_LOAD_A(0, ra0) H3_LOAD_A(1, ra1) H3_LOAD_A(2, ra2) H3_LOAD_A(3, ra3)                    \
-        const uint8_t* wrow = wg + (long)r0 * p.w_row_bytes + (long)(q_) * 128 + u * 16;           \
-        H3_LOAD_B(0, rb0) H3_LOAD_B(1, rb1) H3_LOAD_B(2, rb2) H3_LOAD_B(3, rb3)                    \
-    }
-#define H3_STORE_CHUNK(buf_)                                                                       \
-    {                                                                                              \
-        uint8_t* a_ = As + (buf_) * BMH * LDB + ldsoff;                                            \
-        uint8_t* b_ = Bs + (buf_) * BNH * LDB + ldsoff;                                            \
-        *reinterpret_cast<uint4*>(a_) = ra0;                                                       \
-        if constexpr (T::A_LOADS > 1) *reinterpret_cast<uint4*>(a_ + 1 * T::ROWS_PER_PASS * LDB) = ra1; \
-        if constexpr (T::A_LOADS > 2) *reinterpret_cast<uint4*>(a_ + 2 * T::ROWS_PER_PASS * LDB) = ra2; \
-        if constexpr (T::A_LOADS > 3) *reinterpret_cast<uint4*>(a_ + 3 * T::ROWS_PER_PASS * LDB) = ra3; \
-        *reinterpret_cast<uint4*>(b_) = rb0;                                                       \
-        if constexpr (T::B_LOADS > 1) *reinterpret_cast<uint4*>(b_ + 1 * T::ROWS_PER_PASS * LDB) = rb1; \
-        if constexpr (T::B_LOADS > 2) *reinterpret_cast<uint4*>(b_ + 2 * T::ROWS_PER_PASS * LDB) = rb2; \
-        if constexpr (T::B_LOADS > 3) *reinterpret_cast<uint4*>(b_ + 3 * T::ROWS_PER_PASS * LDB) = rb3; \
-    }
     // ---- LDS-DMA issue of one chunk ----------------------------------------------------------
     // per-thread invariants: abase[j] = address of this thread's 16-byte unit at tap (0,0) of row j
     // (a virtual address when that tap is padding: only dereferenced when in bounds);
@@ -270,7 +231,8 @@ void conv_igemm_h3(ConvParamsH p) {
         }
     }
 
-    if constexpr (DMA) {
+    static_assert(DMA, "the register-staged variant was retired: LDS-DMA staging measured 10-15 % faster");
+    {
         // LDS ring of NST slots, NST-1 chunks of LDS-DMA in flight.  The wait in front of each
         // barrier is a COUNTED vmcnt (everything but this thread's newest NST-2 chunks), the barrier
         // a raw s_barrier (__syncthreads() would always drain with vmcnt(0)), and a slot is read one
@@ -301,20 +263,6 @@ void conv_igemm_h3(ConvParamsH p) {
             }
             slot = slot == NST - 1 ? 0 : slot + 1;
         }
-    } else {
-        H3_LOAD_CHUNK(0)
-        H3_STORE_CHUNK(0)
-        __syncthreads();
-        for (int q = 0; q + 1 < p.nchunks; ++q) {
-            const int buf = q & 1;
-            H3_LOAD_CHUNK(q + 1)
-            __builtin_amdgcn_sched_barrier(0);
-            H3_COMPUTE(buf)
-            __builtin_amdgcn_sched_barrier(0);
-            H3_STORE_CHUNK(buf ^ 1)
-            __syncthreads();
-        }
-        H3_COMPUTE((p.nchunks - 1) & 1)
     }
 
     // ---- epilogue: combine, bias, ReLU; store float32 or re-split for the next layer ---------
@@ -358,13 +306,9 @@ void conv_igemm_h3(ConvParamsH p) {
     }
 }
 
-#undef H3_LOAD_A
 #undef H3_DMA_A
 #undef H3_DMA_B
 #undef H3_DMA_CHUNK
-#undef H3_LOAD_B
-#undef H3_LOAD_CHUNK
-#undef H3_STORE_CHUNK
 #undef H3_COMPUTE
 
 }  // namespace davo

@@ -245,77 +245,70 @@ std::vector<Launch> plan_layer(int mtiles, int npad, int groups) {
 
 // ---- f16x3 path: tile shapes, weight packing, dispatch --------------------------------------
 // tile id -> (WM, WN, TM, TN): BM = WM*TM*32, BN = WN*TN*32, threads = WM*WN*64
-enum { TILE_128x32 = 0, TILE_256x64 = 1, TILE_256x128 = 2, TILE_128x256 = 3, TILE_128x128 = 4, TILE_256x256 = 5, TILE_256x256_W16 = 6, NUM_TILES = 7 };
+enum { TILE_128x32 = 0, TILE_256x64 = 1, TILE_256x128 = 2, TILE_128x256 = 3, TILE_128x128 = 4, TILE_256x256 = 5, NUM_TILES = 6 };
 struct TileShape { int bm, bn, threads, lds; };
 TileShape tile_shape(int t) {
     switch (t) {
-        case TILE_128x32: return {128, 32, 256, TileH<4, 1, 1, 1>::LDS_BYTES};
-        case TILE_256x64: return {256, 64, 512, TileH<4, 2, 2, 1>::LDS_BYTES};
-        case TILE_256x128: return {256, 128, 512, TileH<4, 2, 2, 2>::LDS_BYTES};
-        case TILE_128x256: return {128, 256, 512, TileH<2, 4, 2, 2>::LDS_BYTES};
-        case TILE_256x256: return {256, 256, 512, TileH<4, 2, 2, 4>::LDS_BYTES};
-        case TILE_256x256_W16: return {256, 256, 1024, TileH<4, 4, 2, 2>::LDS_BYTES};
-        default: return {128, 128, 512, TileH<4, 2, 1, 2>::LDS_BYTES};
+        case TILE_128x32: return {128, 32, 256, TileH<4, 1, 1, 1>::LDS_BYTES_DMA};
+        case TILE_256x64: return {256, 64, 512, TileH<4, 2, 2, 1>::LDS_BYTES_DMA};
+        case TILE_256x128: return {256, 128, 512, TileH<4, 2, 2, 2>::LDS_BYTES_DMA};
+        case TILE_128x256: return {128, 256, 512, TileH<2, 4, 2, 2>::LDS_BYTES_DMA};
+        case TILE_256x256: return {256, 256, 512, TileH<4, 2, 2, 4>::LDS_BYTES_DMA};
+        default: return {128, 128, 512, TileH<4, 2, 1, 2>::LDS_BYTES_DMA};
     }
 }
 
-bool h3_use_dma() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DAVO_H3_DMA"); v = e ? atoi(e) : 1; }
-    return v != 0;
-}
-
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC>
+// All f16x3 launches are LDS-DMA staged.  SMALLC (Cin < 32) is a property of the layer.
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool SMALLC>
 hipError_t launch_h3_c(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
     using T = TileH<WM, WN, TM, TN>;
-    constexpr int lds = DMA ? T::LDS_BYTES_DMA : T::LDS_BYTES;
-    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, DMA, SMALLC>;
+    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, true, SMALLC>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES_DMA);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(T::THREADS), lds, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(T::THREADS), T::LDS_BYTES_DMA, s, p);
     return hipGetLastError();
 }
 
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA>
-hipError_t launch_h3_d(const ConvParamsH& p, dim3 grid, hipStream_t s) {
-    return p.cb_log2 < 5 ? launch_h3_c<KS, STRIDE, WM, WN, TM, TN, LAYER, DMA, true>(p, grid, s)
-                         : launch_h3_c<KS, STRIDE, WM, WN, TM, TN, LAYER, DMA, false>(p, grid, s);
-}
-
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER>
-hipError_t launch_h3_t(const ConvParamsH& p, dim3 grid, hipStream_t s) {
-    return h3_use_dma() ? launch_h3_d<KS, STRIDE, WM, WN, TM, TN, LAYER, true>(p, grid, s)
-                        : launch_h3_d<KS, STRIDE, WM, WN, TM, TN, LAYER, false>(p, grid, s);
-}
-
-template <int KS, int STRIDE, int LAYER>
+// MAXBN bounds the instantiations to the N tiles a layer can use (its padded Cout)
+template <int KS, int STRIDE, int LAYER, bool SMALLC, int MAXBN>
 hipError_t launch_h3_tile(int tile, const ConvParamsH& p, dim3 grid, hipStream_t s) {
-    switch (tile) {
-        case TILE_128x32: return launch_h3_t<KS, STRIDE, 4, 1, 1, 1, LAYER>(p, grid, s);
-        case TILE_256x64: return launch_h3_t<KS, STRIDE, 4, 2, 2, 1, LAYER>(p, grid, s);
-        case TILE_256x128: return launch_h3_t<KS, STRIDE, 4, 2, 2, 2, LAYER>(p, grid, s);
-        case TILE_128x256: return launch_h3_t<KS, STRIDE, 2, 4, 2, 2, LAYER>(p, grid, s);
-        case TILE_128x128: return launch_h3_t<KS, STRIDE, 4, 2, 1, 2, LAYER>(p, grid, s);
-        case TILE_256x256: return launch_h3_t<KS, STRIDE, 4, 2, 2, 4, LAYER>(p, grid, s);
-        case TILE_256x256_W16: return launch_h3_t<KS, STRIDE, 4, 4, 2, 2, LAYER>(p, grid, s);
+    if (tile == TILE_128x32) return launch_h3_c<KS, STRIDE, 4, 1, 1, 1, LAYER, SMALLC>(p, grid, s);
+    if constexpr (MAXBN >= 64)
+        if (tile == TILE_256x64) return launch_h3_c<KS, STRIDE, 4, 2, 2, 1, LAYER, SMALLC>(p, grid, s);
+    if constexpr (MAXBN >= 128) {
+        if (tile == TILE_256x128) return launch_h3_c<KS, STRIDE, 4, 2, 2, 2, LAYER, SMALLC>(p, grid, s);
+        if (tile == TILE_128x128) return launch_h3_c<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC>(p, grid, s);
     }
+    if constexpr (MAXBN >= 256 && LAYER != 0) {
+        if (tile == TILE_128x256) return launch_h3_c<KS, STRIDE, 2, 4, 2, 2, LAYER, SMALLC>(p, grid, s);
+        if (tile == TILE_256x256) return launch_h3_c<KS, STRIDE, 4, 2, 2, 4, LAYER, SMALLC>(p, grid, s);
+    }
+    if constexpr (MAXBN >= 256 && LAYER == 0)
+        if (tile == TILE_128x256) return launch_h3_c<KS, STRIDE, 2, 4, 2, 2, LAYER, SMALLC>(p, grid, s);
     return hipErrorInvalidValue;
+}
+
+// generic shapes (davo_conv2d_same): SMALLC follows the channel-block size
+template <int KS, int STRIDE>
+hipError_t launch_h3_generic(int tile, const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    return p.cb_log2 < 5 ? launch_h3_tile<KS, STRIDE, 0, true, 256>(tile, p, grid, s)
+                         : launch_h3_tile<KS, STRIDE, 0, false, 256>(tile, p, grid, s);
 }
 
 hipError_t launch_layer_h3(int layer, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s) {
     switch (layer) {
-        case 0: return launch_h3_tile<7, 2, 1>(tile, p, grid, s);
-        case 1: return launch_h3_tile<5, 2, 2>(tile, p, grid, s);
-        case 2: return launch_h3_tile<3, 1, 3>(tile, p, grid, s);
-        case 3: return launch_h3_tile<3, 1, 4>(tile, p, grid, s);
-        case 4: return launch_h3_tile<3, 1, 5>(tile, p, grid, s);
-        case 5: return launch_h3_tile<3, 1, 6>(tile, p, grid, s);
-        case 6: return launch_h3_tile<3, 2, 7>(tile, p, grid, s);
+        case 0: return launch_h3_tile<7, 2, 1, true, 32>(tile, p, grid, s);
+        case 1: return launch_h3_tile<5, 2, 2, true, 32>(tile, p, grid, s);
+        case 2: return launch_h3_tile<3, 1, 3, false, 64>(tile, p, grid, s);
+        case 3: return launch_h3_tile<3, 1, 4, false, 128>(tile, p, grid, s);
+        case 4: return launch_h3_tile<3, 1, 5, false, 256>(tile, p, grid, s);
+        case 5: return launch_h3_tile<3, 1, 6, false, 256>(tile, p, grid, s);
+        case 6: return launch_h3_tile<3, 2, 7, false, 256>(tile, p, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1282,15 +1275,15 @@ int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, c
             dim3 grid((p.M + ts.bm - 1) / ts.bm * p.ntiles_n, 1);
             hipError_t le = hipErrorInvalidValue;
             if (stride == 1) {
-                if (k == 1) le = launch_h3_tile<1, 1, 0>(tile, p, grid, nullptr);
-                if (k == 3) le = launch_h3_tile<3, 1, 0>(tile, p, grid, nullptr);
-                if (k == 5) le = launch_h3_tile<5, 1, 0>(tile, p, grid, nullptr);
-                if (k == 7) le = launch_h3_tile<7, 1, 0>(tile, p, grid, nullptr);
+                if (k == 1) le = launch_h3_generic<1, 1>(tile, p, grid, nullptr);
+                if (k == 3) le = launch_h3_generic<3, 1>(tile, p, grid, nullptr);
+                if (k == 5) le = launch_h3_generic<5, 1>(tile, p, grid, nullptr);
+                if (k == 7) le = launch_h3_generic<7, 1>(tile, p, grid, nullptr);
             } else {
-                if (k == 1) le = launch_h3_tile<1, 2, 0>(tile, p, grid, nullptr);
-                if (k == 3) le = launch_h3_tile<3, 2, 0>(tile, p, grid, nullptr);
-                if (k == 5) le = launch_h3_tile<5, 2, 0>(tile, p, grid, nullptr);
-                if (k == 7) le = launch_h3_tile<7, 2, 0>(tile, p, grid, nullptr);
+                if (k == 1) le = launch_h3_generic<1, 2>(tile, p, grid, nullptr);
+                if (k == 3) le = launch_h3_generic<3, 2>(tile, p, grid, nullptr);
+                if (k == 5) le = launch_h3_generic<5, 2>(tile, p, grid, nullptr);
+                if (k == 7) le = launch_h3_generic<7, 2>(tile, p, grid, nullptr);
             }
             chk(le);
         } else {
