@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "conv_igemm_h3.h"
+#include "prologue.h"
 
 namespace davo {
 
@@ -45,10 +46,23 @@ struct ConvPatchParams {
     uint8_t* y;             // split-fp16 blocked output [NB][Ho][Wo][16 hi | 16 lo]
     const uint8_t* zeros;
     int H, W, Ho, Wo, pad_t, pad_l;
-    int tiles_x, tiles_y;
+    int tiles_x, tiles_y, ntiles;
     float out_scale;
+    // FUSED = true: the patch is built from the raw inputs (mask + pack fused in, the packed tensor
+    // is never materialised): davo.py:1519-1522 (u8 -> f32), :1115,1178 (LUT attention), :1404-1442
+    const uint8_t* img;     // u8 [B][H][3W][3]
+    const float* flow;      // [B][4][H][W][2]
+    const float* seg;       // [B][3][H][W][1]
+    const float* tab;       // [B][3][19] attention tables (se_excite)
+    Variant v;
 };
 
+// Persistent form: the grid is 2 workgroups per CU; each stages the 28 KB of B fragments once and
+// then walks its share of the output tiles (tile t, t + gridDim.x, ...), re-filling only the 25 KB
+// input patch per tile.  With one launch-wide weight fetch instead of one per tile the kernel's
+// L2 -> LDS traffic halves (it was bound by exactly that).  Two co-resident workgroups overlap each
+// other's fill / matrix / store phases.
+template <bool FUSED>
 __global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchParams p) {
     using namespace cp1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_p[];
@@ -57,76 +71,138 @@ __global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchP
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = blockIdx.x;
-    const int tx = b % p.tiles_x; b /= p.tiles_x;
-    const int ty = b % p.tiles_y; const int n = b / p.tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy_base = oy0 * 2 - p.pad_t, ix_base = ox0 * 2 - p.pad_l;
-
-    // ---- stage patch + weights by LDS-DMA: one wave-instruction = 64 units = 2 (py,parity) rows
-    const uint8_t* xin = p.x + (size_t)n * p.H * p.W * 32;
-    constexpr int PATCH_INSTR = PH;                            // per plane: one instruction = one py, both parities
-    for (int k = wave; k < 2 * PATCH_INSTR; k += 4) {
-        const int plane = k / PATCH_INSTR;
-        const int py = k - plane * PATCH_INSTR, par = lane >> 5, px2 = lane & 31;
-        const int iy = iy_base + py, ix = ix_base + 2 * px2 + par;
-        const bool ok = px2 * 2 + par < PW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const uint8_t* src = ok ? xin + ((size_t)iy * p.W + ix) * 32 + plane * 16 : p.zeros;
-        __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(patch + k * 1024), 16, 0, 0);
-    }
     for (int k = wave; k < WBYTES / 1024; k += 4)
         __builtin_amdgcn_global_load_lds((gptr_t*)(p.w + (size_t)k * 1024 + lane * 16), (lptr_t*)(wl + k * 1024), 16, 0, 0);
 
-    // ---- accumulators: 2 subtiles per wave (output rows 2*wave, 2*wave+1), start at bias / out_scale
     const int r = lane & 15, kq = lane >> 4;
     const float bv = p.bias[r] * (1.0f / p.out_scale);         // C/D layout: col = lane & 15
-    f32x4 acc0 = {bv, bv, bv, bv}, acc1 = acc0;
     // A fragment address of subtile row oy_l: py = 2*oy_l + ky, px = 2*r + 4*h + kq
     const int a_lane = (kq & 1) * ROWB + (r + (kq >> 1)) * 16;
     const uint8_t* a0 = patch + (2 * (2 * wave) * 2) * ROWB + a_lane;
     const uint8_t* a1 = patch + (2 * (2 * wave + 1) * 2) * ROWB + a_lane;
     const uint8_t* wb = wl + lane * 16;
-    __syncthreads();                                           // drains the LDS-DMA (vmcnt(0)) + barrier
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
 
+    // stage one tile's patch.  !FUSED: LDS-DMA from the packed tensor, one wave-instruction = 64 units
+    // = one py, both parities.  FUSED: every thread builds 3-4 patch pixels from the raw inputs
+    // (same arithmetic as mask_pack<16>) and writes their hi / lo units.
+    auto issue_patch = [&](int t) {
+        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
+        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+        const int iy_base = ty * TH * 2 - p.pad_t, ix_base = tx * TW * 2 - p.pad_l;
+        if constexpr (!FUSED) {
+            const uint8_t* xin = p.x + (size_t)n * p.H * p.W * 32;
+            for (int k = wave; k < 2 * PH; k += 4) {
+                const int plane = k / PH;
+                const int py = k - plane * PH, par = lane >> 5, px2 = lane & 31;
+                const int iy = iy_base + py, ix = ix_base + 2 * px2 + par;
+                const bool ok = px2 * 2 + par < PW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const uint8_t* src = ok ? xin + ((size_t)iy * p.W + ix) * 32 + plane * 16 : p.zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(patch + k * 1024), 16, 0, 0);
+            }
+        } else {
+            const int b = n >> 1, s = n & 1;
+            const Variant& v = p.v;
+            const size_t HW = (size_t)p.H * p.W;
+            const float* tab_s = p.tab + ((size_t)b * 3 + 1 + s) * NCLS;
+            const float* tab_t = p.tab + (size_t)b * 3 * NCLS;
+            // PW + 1 columns: unit (parity 1, px2 = 18) is read by the zero-weight dummy tap kx = 7 of
+            // the last output column and must hold finite data (0 x NaN would poison the sum)
+            constexpr int PWF = PW + 1;
+            for (int idx = tid; idx < PH * PWF; idx += THREADS) {
+                const int py = idx / PWF, px = idx - py * PWF;
+                const int iy = iy_base + py, ix = ix_base + px;
+                float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                    const uint8_t* row = p.img + ((size_t)b * p.H + iy) * (size_t)(9 * p.W);
+                    const uint8_t* pt = row + (size_t)(p.W + ix) * 3;
+                    const uint8_t* ps = row + (size_t)((s ? 2 * p.W : 0) + ix) * 3;
+                    const size_t pix = (size_t)iy * p.W + ix;
+                    float as = 1.f, at = 1.f;
+                    if (v.att_source != 0) as = att_lookup(tab_s, p.seg[((size_t)b * 3 + (s ? 2 : 0)) * HW + pix]);
+                    if (v.att_source == 3) at = att_lookup(tab_t, p.seg[((size_t)b * 3 + 1) * HW + pix]);
+                    r[0] = u8_to_unit(pt[0]); r[1] = u8_to_unit(pt[1]); r[2] = u8_to_unit(pt[2]);
+                    r[3] = u8_to_unit(ps[0]); r[4] = u8_to_unit(ps[1]); r[5] = u8_to_unit(ps[2]);
+                    if (v.mask_rgb) {
+                        r[0] *= at; r[1] *= at; r[2] *= at;
+                        r[3] *= as; r[4] *= as; r[5] *= as;
+                    }
+                    if (v.cin_per_frame == 5) {
+                        const float2 f = *reinterpret_cast<const float2*>(p.flow + (((size_t)b * 4 + s) * HW + pix) * 2);
+                        r[6] = v.mask_info ? f.x * as : f.x;
+                        r[7] = v.mask_info ? f.y * as : f.y;
+                    }
+                }
+                _Float16 hl[16];
 #pragma unroll
-    for (int step = 0; step < STEPS; ++step) {
-        const int ky = step >> 1, h = step & 1;
-        const int aoff = ky * 2 * ROWB + h * 32;               // filter row, +2 units for taps 4..7
-        const half8 bh = lds_frag(wb + (step * 2) * 1024);
-        const half8 bl = lds_frag(wb + (step * 2 + 1) * 1024);
-        const half8 ah0 = lds_frag(a0 + aoff), al0 = lds_frag(a0 + aoff + PLANE);
-        const half8 ah1 = lds_frag(a1 + aoff), al1 = lds_frag(a1 + aoff + PLANE);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, acc1, 0, 0, 0);
-    }
-
-    // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel), row = 4*(lane>>4) + i (pixel)
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-        const int oy = oy0 + 2 * wave + sub;
-        if (oy >= p.Ho) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ox = ox0 + 4 * kq + i;
-            float v = (sub == 0 ? acc0[i] : acc1[i]) * p.out_scale;
-            v = fminf(fmaxf(v, 0.f), 65504.f);
-            if (ox < p.Wo) {
-                // even lanes store the hi halves of channels (n, n+1), odd lanes the lo halves of (n-1, n)
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
-                                   ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
-                const bool odd = r & 1;
-                const unsigned word = odd ? ((xn >> 16) | (x & 0xffff0000u)) : ((x & 0xffffu) | (xn << 16));
-                uint8_t* o = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + (odd ? 32 + (r - 1) * 2 : r * 2);
-                *reinterpret_cast<unsigned*>(o) = word;
+                for (int k = 0; k < 8; ++k) {
+                    const _Float16 h = (_Float16)r[k];
+                    hl[k] = h;
+                    hl[8 + k] = (_Float16)(r[k] - (float)h);
+                }
+                uint8_t* dst = patch + (py * 2 + (px & 1)) * ROWB + (px >> 1) * 16;
+                *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(&hl[0]);
+                *reinterpret_cast<float4*>(dst + PLANE) = *reinterpret_cast<const float4*>(&hl[8]);
             }
         }
+    };
+
+    int t = blockIdx.x;
+    if (t < p.ntiles) issue_patch(t);
+    while (t < p.ntiles) {
+        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
+        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        // explicit drain: when ordinary loads are mixed with LDS-DMA (FUSED fill after the weight DMA)
+        // hipcc's own vmcnt bookkeeping does not reliably cover the DMA before the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        f32x4 acc0 = {bv, bv, bv, bv}, acc1 = acc0;
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step) {
+            const int ky = step >> 1, h = step & 1;
+            const int aoff = ky * 2 * ROWB + h * 32;           // filter row, +2 units for taps 4..7
+            const half8 bh = lds_frag(wb + (step * 2) * 1024);
+            const half8 bl = lds_frag(wb + (step * 2 + 1) * 1024);
+            const half8 ah0 = lds_frag(a0 + aoff), al0 = lds_frag(a0 + aoff + PLANE);
+            const half8 ah1 = lds_frag(a1 + aoff), al1 = lds_frag(a1 + aoff + PLANE);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, acc1, 0, 0, 0);
+        }
+        __syncthreads();                                       // every wave is done reading the patch
+        const int tnext = t + gridDim.x;
+        if (tnext < p.ntiles) issue_patch(tnext);              // the refill flies under this tile's stores
+
+        // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel), row = 4*(lane>>4) + i (pixel)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int oy = oy0 + 2 * wave + sub;
+            if (oy >= p.Ho) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ox = ox0 + 4 * kq + i;
+                float v = (sub == 0 ? acc0[i] : acc1[i]) * p.out_scale;
+                v = fminf(fmaxf(v, 0.f), 65504.f);
+                if (ox < p.Wo) {
+                    // even lanes store the hi halves of channels (n, n+1), odd lanes the lo halves of (n-1, n)
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+                    const bool odd = r & 1;
+                    const unsigned word = odd ? ((xn >> 16) | (x & 0xffff0000u)) : ((x & 0xffffu) | (xn << 16));
+                    uint8_t* o = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + (odd ? 32 + (r - 1) * 2 : r * 2);
+                    *reinterpret_cast<unsigned*>(o) = word;
+                }
+            }
+        }
+        t = tnext;
     }
 }
 

@@ -96,6 +96,8 @@ struct davo_ctx {
     int act_ch[7];
     int packed_ld = 8;
     int last_B = 0;
+    bool packed_valid = true;                  // false when cnv1 consumed the raw inputs directly (fused)
+    const void *last_img = nullptr, *last_flow = nullptr, *last_seg = nullptr;
     int last_plan[7][2] = {};                  // per layer, per launch: mtiles*1000 + BN (reported by the bench)
     // host-API staging
     void *s_img = nullptr, *s_flow = nullptr, *s_seg = nullptr, *s_pose = nullptr;
@@ -783,27 +785,35 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
     return DAVO_OK;
 }
 
-// cnv1 of the f16x3 path from an LDS-staged input patch (conv_patch_h3.h)
-int run_cnv1_patch(davo_ctx* c, const void* x, void* y, int NB) {
+// cnv1 of the f16x3 path from an LDS-staged input patch (conv_patch_h3.h).  fused: the patch is built
+// from the raw inputs (mask + pack fused in); otherwise it is copied from the packed tensor.
+int run_cnv1_patch(davo_ctx* c, bool fused, const void* d_img, const void* d_flow, const void* d_seg, void* y, int NB) {
     static bool attr_set = false;
     const ConvLayer& L = c->L[0];
     ConvPatchParams p{};
     int Ho, Wo, pt, pl;
     same_pad(c->H, 7, 2, 1, &Ho, &pt);
     same_pad(c->W, 7, 2, 1, &Wo, &pl);
-    p.x = static_cast<const uint8_t*>(x); p.w = c->d_w1patch; p.bias = L.d_bh; p.y = static_cast<uint8_t*>(y);
+    p.x = reinterpret_cast<const uint8_t*>(c->d_packed); p.w = c->d_w1patch; p.bias = L.d_bh; p.y = static_cast<uint8_t*>(y);
     p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
     p.H = c->H; p.W = c->W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pt; p.pad_l = pl;
     p.tiles_x = (Wo + cp1::TW - 1) / cp1::TW; p.tiles_y = (Ho + cp1::TH - 1) / cp1::TH;
     p.out_scale = 1.0f / L.wscale;
+    p.ntiles = NB * p.tiles_x * p.tiles_y;
+    p.img = static_cast<const uint8_t*>(d_img); p.flow = static_cast<const float*>(d_flow);
+    p.seg = static_cast<const float*>(d_seg); p.tab = c->d_tab; p.v = c->v;
     if (!attr_set) {
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_cnv1_h3),
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_cnv1_h3<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, cp1::LDS_BYTES));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_cnv1_h3<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, cp1::LDS_BYTES));
         attr_set = true;
     }
     c->last_plan[0][0] = ((NB * Ho * Wo + 127) / 128) * 1000 + 99; c->last_plan[0][1] = 0;
+    const int nblk = p.ntiles < 512 ? p.ntiles : 512;          // 2 workgroups per CU, each walks its tiles
     ProfScope ps(c, "cnv1");
-    hipLaunchKernelGGL(conv_patch_cnv1_h3, dim3(NB * p.tiles_x * p.tiles_y), dim3(cp1::THREADS), cp1::LDS_BYTES, c->stream, p);
+    if (fused) hipLaunchKernelGGL(conv_patch_cnv1_h3<true>, dim3(nblk), dim3(cp1::THREADS), cp1::LDS_BYTES, c->stream, p);
+    else hipLaunchKernelGGL(conv_patch_cnv1_h3<false>, dim3(nblk), dim3(cp1::THREADS), cp1::LDS_BYTES, c->stream, p);
     HIP_TRY(c, hipGetLastError());
     return DAVO_OK;
 }
@@ -856,9 +866,17 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         HIP_TRY(c, hipGetLastError());
     }
     const long nthreads = (long)NB * H * (W / 4);
+    // f16x3, DAVO_FUSE_PACK=1: cnv1 builds its input patch straight from the raw inputs (mask + pack fused in,
+    // the packed tensor never touches HBM).  Measured equal in time to mask_pack + cnv1 (the fused fill is bound
+    // by its byte loads), so the two-kernel form stays the default.
+    static const bool fuse_env = getenv("DAVO_FUSE_PACK") && atoi(getenv("DAVO_FUSE_PACK")) == 1;
+    static const bool patch1 = !(getenv("DAVO_CNV1_PATCH") && atoi(getenv("DAVO_CNV1_PATCH")) == 0);
+    const bool fused = h3 && patch1 && fuse_env;
+    c->packed_valid = !fused;
+    c->last_img = d_img; c->last_flow = d_flow; c->last_seg = d_seg;
     c->packed_ld = c->impl == 0 ? 8 : 10;
     (void)0;
-    {
+    if (!fused) {
         ProfScope ps(c, "mask_pack");
         if (h3)
             hipLaunchKernelGGL(mask_pack<16>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s,
@@ -878,8 +896,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     float** a = c->d_act;
     int rc;
     if (h3) {
-        static const bool patch1 = !(getenv("DAVO_CNV1_PATCH") && atoi(getenv("DAVO_CNV1_PATCH")) == 0);
-        if (patch1) { if ((rc = run_cnv1_patch(c, c->d_packed, a[0], NB))) return rc; }
+        if (patch1) { if ((rc = run_cnv1_patch(c, fused, d_img, d_flow, d_seg, a[0], NB))) return rc; }
         else if ((rc = run_conv_layer_h3(c, 0, c->d_packed, 8, H, W, a[0], 16, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, false, NB))) return rc;
@@ -1176,7 +1193,17 @@ int davo_debug_read(davo_ctx* c, const char* tensor, float* host_out, size_t n_f
     size_t n = 0;
     const std::string t = tensor;
     if (t == "att_table") { src = c->d_tab; n = (size_t)c->last_B * 3 * NCLS; }
-    else if (t == "packed") { src = c->d_packed; n = NB * c->H * c->W * c->packed_ld; }
+    else if (t == "packed") {
+        if (!c->packed_valid) {          // fused path: materialise the packed tensor on demand from the last inputs
+            const long nthreads = (long)NB * c->H * (c->W / 4);
+            hipLaunchKernelGGL(mask_pack<16>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream,
+                               static_cast<const uint8_t*>(c->last_img), static_cast<const float*>(c->last_flow),
+                               static_cast<const float*>(c->last_seg), c->d_tab, c->v, c->last_B, c->H, c->W, c->d_packed);
+            HIP_TRY(c, hipGetLastError());
+            c->packed_valid = true;
+        }
+        src = c->d_packed; n = NB * c->H * c->W * c->packed_ld;
+    }
     else {
         const char* names[7] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6", "cnv7"};
         for (int i = 0; i < 7; ++i)

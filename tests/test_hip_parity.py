@@ -279,3 +279,25 @@ def test_config5_256x832(c_oracle):
         e = _engine(cfg, 256, 832, 2, weights, prec)
         assert_pose_close(e.forward(img, flow, seg), want, "256x832 %s" % prec)
         e.close()
+
+
+def test_fused_pack_cnv1_variant(monkeypatch, c_oracle):
+    """DAVO_FUSE_PACK=1: cnv1 builds its patch from the raw inputs (mask + pack fused in).  The env var is
+    read once per process at the first forward, so this runs the engine in a child process."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from davo_amd import Engine, synth, parse_version, FLAGSHIP_VERSION\n"
+        "from oracle import c_oracle\n"
+        "cfg = parse_version(FLAGSHIP_VERSION); w = synth.make_weights(cfg)\n"
+        "for B, H, W in ((3, 128, 416), (2, 36, 100)):\n"
+        "    img, flow, seg = synth.make_inputs(B, H, W)\n"
+        "    e = Engine(cfg, H, W, B); e.load_weights(w)\n"
+        "    got = e.forward(img, flow, seg); want = c_oracle.forward(cfg, img, flow, seg, w)\n"
+        "    err = float(np.abs(got - want).max()); assert err <= 1e-4 * float(np.abs(want).max()), err\n"
+        "    assert 'mask_pack' not in e.profile_entries()\n"
+        "print('fused ok')\n" % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    env = dict(__import__("os").environ, DAVO_FUSE_PACK="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "fused ok" in out.stdout, out.stderr[-2000:]
