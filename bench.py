@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic windows generated per rank (tiled to the batch)")
     ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
                     help="f16x3: split-fp16 MFMA, float32-grade (default); f32: FP32 MFMA, bit-exact fmaf chains")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches kept in flight on the GPU (davo_set_inflight): 2 = the next batch's small kernels "
+                         "overlap this batch's large convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="triplets per CPU-baseline pass")
     return ap.parse_args()
@@ -107,17 +110,23 @@ def main():
     eng.load_weights(weights)
     eng.set_precision(args.precision)
 
-    # synthetic windows of this rank's shard, resident in HBM before the timed region
+    # synthetic windows of this rank's shard, resident in HBM before the timed region; one buffer set per
+    # in-flight slot (consecutive steps work on different batches of the shard)
     nu = max(1, min(args.unique, B))
-    img_u, flow_u, seg_u = synth.make_inputs(nu, H, W, first_window=rank * B)
-    reps = -(-B // nu)
-    img = np.tile(img_u, (reps, 1, 1, 1))[:B]
-    flow = np.tile(flow_u, (reps, 1, 1, 1, 1))[:B]
-    seg = np.tile(seg_u, (reps, 1, 1, 1, 1))[:B]
-    d_img = eng.alloc(img.nbytes).upload(img)
-    d_flow = eng.alloc(flow.nbytes).upload(flow)
-    d_seg = eng.alloc(seg.nbytes).upload(seg)
-    d_pose = eng.alloc(B * 12 * 4)
+    nset = max(1, args.inflight)
+    sets = []
+    for k in range(nset):
+        img_u, flow_u, seg_u = synth.make_inputs(nu, H, W, first_window=(rank * nset + k) * B)
+        reps = -(-B // nu)
+        img_k = np.tile(img_u, (reps, 1, 1, 1))[:B]
+        flow_k = np.tile(flow_u, (reps, 1, 1, 1, 1))[:B]
+        seg_k = np.tile(seg_u, (reps, 1, 1, 1, 1))[:B]
+        sets.append((eng.alloc(img_k.nbytes).upload(img_k), eng.alloc(flow_k.nbytes).upload(flow_k),
+                     eng.alloc(seg_k.nbytes).upload(seg_k), eng.alloc(B * 12 * 4)))
+        if k == 0:
+            img, flow, seg = img_k, flow_k, seg_k
+    d_img, d_flow, d_seg, d_pose = sets[0]
+    eng.set_inflight(nset)
 
     def sync_all():
         eng.synchronize()
@@ -127,8 +136,8 @@ def main():
         eng.synchronize()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.forward_device(B, d_img, d_flow, d_seg, d_pose)
+    for i in range(args.warmup):
+        eng.forward_device(B, *sets[i % nset])
     eng.synchronize()
 
     # timed region: K steps; only the dominant kernel (main cnv6 launch) is bracketed by HIP events
@@ -137,12 +146,13 @@ def main():
     eng.profile_reset()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.forward_device(B, d_img, d_flow, d_seg, d_pose)
+    for i in range(args.steps):
+        eng.forward_device(B, *sets[i % nset])
     sync_all()
     elapsed = time.perf_counter() - t0
     dominant = eng.profile_entries()
-    # untimed extra pass: per-kernel breakdown (every launch bracketed)
+    # untimed extra pass, one batch in flight: per-kernel breakdown (every launch bracketed)
+    eng.set_inflight(1)
     eng.profile(1)
     eng.profile_reset()
     for _ in range(max(3, args.steps // 4)):
@@ -248,7 +258,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: single MI355X, batch=%d synthetic %dx%d RGB+flow+seg "
                                    "triplets, dilatedPoseNN-cnv6_128 + se_flow + fc_tanh" % (B, H, W),
                        "version": FLAGSHIP_VERSION, "batch_per_gpu": B, "height": H, "width": W,
-                       "parallelism": "window-sharded replicas x%d" % world},
+                       "parallelism": "window-sharded replicas x%d" % world, "batches_in_flight": nset},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
@@ -289,8 +299,9 @@ def main():
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
 
-    for b in (d_img, d_flow, d_seg, d_pose):
-        b.free()
+    for st in sets:
+        for b in st:
+            b.free()
     eng.close()
     if world > 1:
         dist.destroy_process_group()

@@ -72,8 +72,18 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
+// One in-flight batch: its own HIP stream and activation workspace.  Weights are shared.
+struct Slot {
+    hipStream_t stream = nullptr;
+    float *d_partial = nullptr, *d_tab = nullptr, *d_packed = nullptr, *d_pose_partial = nullptr;
+    float* d_act[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
 struct davo_ctx {
     int device = 0, H = 0, W = 0, max_batch = 0;
+    std::vector<Slot> slots;                   // slots[0] is created by davo_create
+    int inflight = 1, next_slot = 0;
+    bool user_stream = false;
     Variant v{};
     int impl = 0;
     int precision = 1;                         // 0 = FP32 MFMA (bit-exact fmaf chains), 1 = f16x3 split (default)
@@ -109,6 +119,24 @@ struct davo_ctx {
 };
 
 namespace {
+
+int fail(davo_ctx* c, int code, const char* fmt, ...);
+
+// bind a slot's stream and workspace to the members every launch helper uses
+void activate_slot(davo_ctx* c, int i) {
+    const Slot& s = c->slots[i];
+    if (!(c->user_stream && i == 0)) c->stream = s.stream;
+    c->d_partial = s.d_partial; c->d_tab = s.d_tab; c->d_packed = s.d_packed; c->d_pose_partial = s.d_pose_partial;
+    for (int k = 0; k < 7; ++k) c->d_act[k] = s.d_act[k];
+}
+
+void free_slot(Slot& s) {
+    for (auto p : s.d_act) if (p) (void)hipFree(p);
+    void* misc[] = {s.d_partial, s.d_tab, s.d_packed, s.d_pose_partial};
+    for (auto p : misc) if (p) (void)hipFree(p);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s = Slot();
+}
 
 int fail(davo_ctx* c, int code, const char* fmt, ...) {
     char buf[1024];
@@ -401,8 +429,10 @@ struct ProfScope {
     }
 };
 
+int sync_all_slots(davo_ctx* c);
+
 int prof_collect(davo_ctx* c) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc = sync_all_slots(c); if (rc) return rc; }
     for (auto& pe : c->prof_entries) {
         for (auto& ab : pe.pending) {
             float ms = 0.f;
@@ -844,6 +874,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     if (!c->packed_ready) { int rc = build_packed_weights(c); if (rc) return rc; }
     const bool h3 = c->impl == 0 && c->precision == 1;
     if (h3 && !c->packed_h_ready) { int rc = build_packed_weights_h3(c); if (rc) return rc; }
+
     const int H = c->H, W = c->W, HW = H * W, NB = 2 * B;
     const Variant& v = c->v;
     hipStream_t s = c->stream;
@@ -944,6 +975,30 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
 
 }  // namespace
 
+namespace {
+
+// allocate one in-flight slot (stream + activation workspace for max_batch triplets)
+int alloc_slot(davo_ctx* c, Slot* s) {
+    const size_t NB = 2 * (size_t)c->max_batch;
+    HIP_TRY(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 7; ++i)
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_act[i]), NB * c->act_floats_per_img[i] * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_packed), NB * (size_t)c->H * c->W * 10 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_partial), (size_t)c->max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_tab), (size_t)c->max_batch * 3 * NCLS * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_pose_partial), NB * 2 * PH_SPLIT * 3 * sizeof(float)));
+    HIP_TRY(c, hipMemset(s->d_partial, 0, (size_t)c->max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
+    return DAVO_OK;
+}
+
+int sync_all_slots(davo_ctx* c) {
+    for (auto& s : c->slots) HIP_TRY(c, hipStreamSynchronize(s.stream));
+    if (c->user_stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DAVO_OK;
+}
+
+}  // namespace
+
 // ============================================================================================
 extern "C" {
 
@@ -965,8 +1020,6 @@ int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const d
     HIP_TRY(c, hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(c, DAVO_ERR_INVALID, "device %d not present (%d visible)", device, ndev);
     HIP_TRY(c, hipSetDevice(device));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
     c->needed = needed_names(c->v);
 
     c->H1 = (H + 1) / 2; c->W1 = (W + 1) / 2;
@@ -988,15 +1041,13 @@ int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const d
     for (int i = 0; i < 7; ++i) {
         c->act_ch[i] = ch[i];
         c->act_floats_per_img[i] = px[i] * ch[i];
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_act[i]), NB * c->act_floats_per_img[i] * sizeof(float)));
     }
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_packed), NB * (size_t)H * W * 10 * sizeof(float)));
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_partial), (size_t)max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_tab), (size_t)max_batch * 3 * NCLS * sizeof(float)));
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_pose_partial), NB * 2 * PH_SPLIT * 3 * sizeof(float)));
+    c->slots.resize(1);
+    { int rc = alloc_slot(c, &c->slots[0]); if (rc) return rc; }
+    c->own_stream = c->slots[0].stream;
+    activate_slot(c, 0);
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_zeros), 256));
     HIP_TRY(c, hipMemset(c->d_zeros, 0, 256));
-    HIP_TRY(c, hipMemset(c->d_partial, 0, (size_t)max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
     return DAVO_OK;
 }
 
@@ -1038,6 +1089,9 @@ int davo_weights_missing(davo_ctx* c) {
 int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg,
                         void* d_pose, float* elapsed_ms) {
     if (!c) return DAVO_ERR_INVALID;
+    // rotate through the in-flight slots: this batch runs on its own stream and workspace
+    activate_slot(c, c->next_slot);
+    c->next_slot = (c->next_slot + 1) % c->inflight;
     if (!elapsed_ms) return forward_device(c, B, d_img, d_flow, d_seg, d_pose);
     HIP_TRY(c, hipSetDevice(c->device));
     hipEvent_t e0, e1;
@@ -1060,6 +1114,8 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
     if (!img || !flow || !seg || !pose_out) return fail(c, DAVO_ERR_INVALID, "null host pointer");
     if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
     HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = sync_all_slots(c); if (rc) return rc; }       // the host path owns the single staging buffer set
+    activate_slot(c, 0);
     const size_t HW = (size_t)c->H * c->W;
     const size_t nb_img = HW * 9, nb_flow = HW * 8 * sizeof(float), nb_seg = HW * 3 * sizeof(float);
     if (!c->s_img) {
@@ -1083,7 +1139,7 @@ const char* davo_last_error(const davo_ctx* c) { return c ? c->err.c_str() : "nu
 void davo_destroy(davo_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)sync_all_slots(c);
     for (auto& kv : c->weights) if (kv.second.dev) (void)hipFree(kv.second.dev);
     for (auto& L : c->L) {
         if (L.d_w) (void)hipFree(L.d_w);
@@ -1091,13 +1147,12 @@ void davo_destroy(davo_ctx* c) {
         if (L.d_wh) (void)hipFree(L.d_wh);
         if (L.d_bh) (void)hipFree(L.d_bh);
     }
-    for (auto p : c->d_act) if (p) (void)hipFree(p);
-    void* misc[] = {c->d_w1patch, c->d_pose_partial, c->d_zeros, c->d_wpred, c->d_bpred, c->d_partial, c->d_tab, c->d_packed, c->s_img, c->s_flow, c->s_seg, c->s_pose};
+    void* misc[] = {c->d_w1patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
     for (auto& pe : c->prof_entries)
         for (auto& ab : pe.pending) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    for (auto& sl : c->slots) free_slot(sl);
     delete c;
 }
 
@@ -1130,11 +1185,12 @@ int davo_memcpy_d2h(davo_ctx* c, void* dst, const void* src, size_t bytes) {
 int davo_synchronize(davo_ctx* c) {
     if (!c) return DAVO_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return DAVO_OK;
+    return sync_all_slots(c);
 }
 int davo_set_stream(davo_ctx* c, void* hip_stream) {
     if (!c) return DAVO_ERR_INVALID;
+    if (hip_stream && c->inflight > 1) return fail(c, DAVO_ERR_INVALID, "a caller-owned stream needs davo_set_inflight(ctx, 1)");
+    c->user_stream = hip_stream != nullptr;
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
     return DAVO_OK;
 }
@@ -1170,6 +1226,21 @@ int davo_last_plan(davo_ctx* c, int layer, int launch, int* mtiles, int* bn) {
     const int v = c->last_plan[layer][launch];
     if (mtiles) *mtiles = v / 1000;
     if (bn) *bn = v % 1000;
+    return DAVO_OK;
+}
+
+int davo_set_inflight(davo_ctx* c, int n) {
+    if (!c || n < 1 || n > 4) return fail(c, DAVO_ERR_INVALID, "inflight must be 1..4");
+    if (n > 1 && c->user_stream) return fail(c, DAVO_ERR_INVALID, "in-flight slots use the context's own streams: clear davo_set_stream first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    while ((int)c->slots.size() < n) {
+        c->slots.emplace_back();
+        int rc = alloc_slot(c, &c->slots.back());
+        if (rc) return rc;
+    }
+    c->inflight = n;
+    c->next_slot = 0;
     return DAVO_OK;
 }
 

@@ -115,6 +115,10 @@ class Engine:
     def synchronize(self):
         self._check(self._L.davo_synchronize(self._ctx))
 
+    def set_inflight(self, n):
+        """Batches kept in flight by forward_device (1..4): n streams + n workspaces, rotated per call."""
+        self._check(self._L.davo_set_inflight(self._ctx, int(n)))
+
     def set_impl(self, impl):
         self._check(self._L.davo_set_impl(self._ctx, {"mfma": 0, "direct": 1}.get(impl, impl)))
 

@@ -89,6 +89,13 @@ int davo_memcpy_d2h(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
 int davo_synchronize(davo_ctx* ctx);
 /* Run on a caller-owned hipStream_t (NULL restores the context's own stream). */
 int davo_set_stream(davo_ctx* ctx, void* hip_stream);
+/* Number of batches davo_forward_device keeps in flight (1..4, default 1).  With n > 1 the context
+ * owns n streams and n activation workspaces and successive calls rotate through them, so the small
+ * kernels of one batch overlap the large convolutions of another (the counterpart of the
+ * reference's tf.data prefetch, data_loader.py:321-324; +11 % throughput at n = 2, B = 32).  The
+ * caller must give concurrent calls distinct input/output buffers and call davo_synchronize()
+ * before reading results.  davo_forward (host buffers) stays synchronous. */
+int davo_set_inflight(davo_ctx* ctx, int n);
 
 /* ---- measurement ---------------------------------------------------------
  * With profiling on, every kernel launch of davo_forward[_device] is bracketed by HIP events

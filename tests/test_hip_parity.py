@@ -301,3 +301,28 @@ def test_fused_pack_cnv1_variant(monkeypatch, c_oracle):
     env = dict(__import__("os").environ, DAVO_FUSE_PACK="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fused ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_two_batches_in_flight(c_oracle):
+    """davo_set_inflight(2): consecutive device calls run on separate streams / workspaces; both results
+    must equal the one-at-a-time results bit for bit."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B = 4
+    weights = synth.make_weights(cfg)
+    batches = [synth.make_inputs(B, 128, 416, first_window=10 * k) for k in range(3)]
+    e = _engine(cfg, 128, 416, B, weights, "f16x3")
+    ref = [e.forward(*b) for b in batches]
+    bufs = []
+    for img, flow, seg in batches:
+        bufs.append((e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48)))
+    e.set_inflight(2)
+    for rep in range(3):
+        for b in bufs:
+            e.forward_device(B, *b)
+    e.synchronize()
+    for k, b in enumerate(bufs):
+        assert np.array_equal(b[3].download((B, 2, 6)), ref[k])
+    assert_pose_close(ref[0], c_oracle.forward(cfg, *batches[0], weights), "in-flight batch 0")
+    e.set_inflight(1)
+    assert np.array_equal(e.forward(*batches[1]), ref[1])
+    e.close()
