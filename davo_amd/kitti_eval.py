@@ -5,7 +5,7 @@ lastFrameFromSegmentLength :58-63, rotationError/translationError :65-78, calcSe
 
 It is a CPU file-to-file tool after the path (O(N) on <= 4.5 k poses), kept on the CPU.  The
 devkit accumulates distances and errors in float32; this restatement does the same so its rows
-agree with the compiled reference (oracle/_ref/test_odometry_all, tests/test_kitti_eval.py).
+agree with the compiled reference evaluator (tests/test_kitti_eval.py builds and runs it).
 """
 import os
 
