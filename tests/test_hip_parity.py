@@ -326,3 +326,19 @@ def test_two_batches_in_flight(c_oracle):
     e.set_inflight(1)
     assert np.array_equal(e.forward(*batches[1]), ref[1])
     e.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_seg_label_edge_values(precision):
+    """tf.cast(float->int32) truncates toward zero and tf.one_hot of an out-of-range id is a zero row
+    (davo.py:1115): fractional, negative and ignore labels must mask exactly like the oracle says."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(2, 64, 96)
+    vals = np.array([0.0, 0.9, 18.0, 18.99, 19.0, 255.0, -0.5, -3.0, 7.5, 100.0], np.float32)
+    rng = np.random.RandomState(3)
+    seg = vals[rng.randint(0, len(vals), size=seg.shape)].astype(np.float32)
+    w = synth.make_weights(cfg)
+    want = O.forward(cfg, img, flow, seg, w)
+    e = _engine(cfg, 64, 96, 2, w, precision)
+    assert_pose_close(e.forward(img, flow, seg), want, "edge labels %s" % precision)
+    e.close()
