@@ -104,3 +104,33 @@ def test_c_oracle_thread_count_invariant(c_oracle):
     a = c_oracle.forward(cfg, img, flow, seg, weights, nthreads=1)
     b = c_oracle.forward(cfg, img, flow, seg, weights, nthreads=4)
     assert np.array_equal(a, b)
+
+
+def test_whole_posenet_vs_torch():
+    """Third opinion on the whole PoseNN (not just one conv): torch-CPU float64 conv2d with explicit TF
+    SAME padding, both heads, pred + mean + 0.01 — against oracle.posenet on the oracle's packed input."""
+    torch = pytest.importorskip("torch")
+    import torch.nn.functional as F
+    g = load_golden()["cases"]["flagship_b3_36x100_ragged"]
+    cfg, img, flow, seg, w = case_inputs(g)
+    packed = O.pack_inputs(cfg, img, flow, seg, w)
+    B, _, H, W, C = packed.shape
+    x = torch.from_numpy(packed.reshape(B * 2, H, W, C)).permute(0, 3, 1, 2)
+
+    def conv(x, name, stride, rate, relu=True):
+        wt = torch.from_numpy(w[name + "/weights"]).double().permute(3, 2, 0, 1)
+        k = wt.shape[-1]
+        _, pt, pb = O.same_pad(x.shape[2], k, stride, rate)
+        _, pl, pr = O.same_pad(x.shape[3], k, stride, rate)
+        y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), wt, torch.from_numpy(w[name + "/biases"]).double(), stride=stride, dilation=rate)
+        return torch.relu(y) if relu else y
+    h = x
+    for name, stride, rate in (("cnv1", 2, 1), ("cnv2", 2, 1), ("cnv3", 1, 2), ("cnv4", 1, 4), ("cnv5", 1, 8)):
+        h = conv(h, "pose_exp_net/" + name, stride, rate)
+    outs = []
+    for head in ("rotation", "translation"):
+        p = "pose_exp_net/pose/%s/" % head
+        c7 = conv(conv(h, p + "cnv6", 1, 2), p + "cnv7", 2, 1)
+        outs.append(conv(c7, p + "pred", 1, 1, relu=False).mean(dim=(2, 3)))
+    pose = (0.01 * torch.cat(outs, dim=1)).numpy().reshape(B, 2, 6)
+    assert np.abs(pose - np.array(g["pose"])).max() < 1e-12
