@@ -16,7 +16,7 @@ EXPORTS = (
     "davo_create", "davo_load_weight", "davo_weights_missing", "davo_forward", "davo_forward_device",
     "davo_last_error", "davo_destroy", "davo_device_malloc", "davo_device_free", "davo_memcpy_h2d",
     "davo_memcpy_d2h", "davo_synchronize", "davo_set_stream", "davo_set_inflight", "davo_profile_enable",
-    "davo_profile_reset", "davo_profile_entry", "davo_last_plan", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
+    "davo_profile_reset", "davo_profile_entry", "davo_last_plan", "davo_set_option", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
 )
 
 
@@ -77,6 +77,7 @@ def lib():
     L.davo_profile_reset.argtypes = [vp]
     L.davo_profile_entry.argtypes = [vp, i, ctypes.c_char_p, i, ctypes.POINTER(i), ctypes.POINTER(ctypes.c_double)]
     L.davo_last_plan.argtypes = [vp, i, i, ctypes.POINTER(i), ctypes.POINTER(i)]
+    L.davo_set_option.argtypes = [vp, ctypes.c_char_p, i]
     L.davo_set_precision.argtypes = [vp, i]
     L.davo_set_impl.argtypes = [vp, i]
     L.davo_debug_read.argtypes = [vp, ctypes.c_char_p, f32p, ctypes.c_size_t]

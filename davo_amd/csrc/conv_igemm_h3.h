@@ -56,6 +56,11 @@ struct ConvParamsH {
     int g_x_boff, g_y_coff;
     long g_w, g_bias;
     float out_scale;        // 1 / (power of two the layer's weights were multiplied by)
+    // y_mode 2 (cnv7 only): the pose head is fused into the epilogue, nothing is stored but this tile's
+    // contribution to sum_pixels sum_channels relu(cnv7) * Wpred[c][k] for the (at most two) images it touches
+    const float* pose_w;    // [groups][256][3] pred kernels
+    float* pose_partial;    // [groups][pose_mt][ntiles_n][2 image slots][3]
+    int pose_P, pose_mt;    // output pixels per image (>= tile height), M tiles in the launch
     int dbg;                // measurement only (DAVO_DBG): bit0 skip the loop's DMA, bit1 skip its MFMA phase
 };
 
@@ -263,6 +268,50 @@ void conv_igemm_h3(ConvParamsH p) {
             }
             slot = slot == NST - 1 ? 0 : slot + 1;
         }
+    }
+
+    // ---- epilogue, pose head fused (y_mode 2): pred is 1x1 linear and the spatial mean is linear
+    // (nets/posenn.py:240-241), so a tile only has to deliver sum_rows sum_cols relu(x) * Wpred[col][k],
+    // split by image.  Fixed summation order -> bitwise reproducible; pose_from_tiles adds the tiles.
+    if (p.y_mode == 2) {
+        const int row0 = mtile * BMH;
+        const int img0 = row0 / p.pose_P;
+        const int split_row = (img0 + 1) * p.pose_P - row0;          // tile rows >= split_row: next image
+        float q[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = ntile * BNH + wn * TN * 32 + j * 32 + li;
+            const float* wp = p.pose_w + ((long)grp * p.Cout + (n < p.Cout ? n : 0)) * 3;
+            const float w0 = n < p.Cout ? wp[0] : 0.f, w1 = n < p.Cout ? wp[1] : 0.f, w2 = n < p.Cout ? wp[2] : 0.f;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = fmaxf(acc[i][j][r] * p.out_scale, 0.f);
+                    if (row0 + row >= p.M) v = 0.f;
+                    if (row < split_row) s0 += v; else s1 += v;
+                }
+            q[0] += s0 * w0; q[1] += s0 * w1; q[2] += s0 * w2;
+            q[3] += s1 * w0; q[4] += s1 * w1; q[5] += s1 * w2;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q[k] += __shfl_down(q[k], o, 64);
+        __syncthreads();                                             // every wave is done with the staging slots
+        float* red = reinterpret_cast<float*>(smem_h);               // [waves][6]
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[wid * 6 + k] = q[k];
+        __syncthreads();
+        if (tid < 6) {
+            float t = 0.f;
+            for (int w = 0; w < WM * WN; ++w) t += red[w * 6 + tid];
+            p.pose_partial[(((long)grp * p.pose_mt + (mtile - p.mtile0)) * p.ntiles_n + ntile) * 6 + tid] = t;
+        }
+        return;
     }
 
     // ---- epilogue: combine, bias, ReLU; store float32 or re-split for the next layer ---------

@@ -84,6 +84,11 @@ struct davo_ctx {
     std::vector<Slot> slots;                   // slots[0] is created by davo_create
     int inflight = 1, next_slot = 0;
     bool user_stream = false;
+    bool opt_fuse_pose = true;                 // f16x3: pose head fused into cnv7's epilogue (davo_set_option)
+    bool opt_fuse_pack = false;                // f16x3: mask+pack fused into cnv1's patch fill
+    float* d_pose_tiles = nullptr;             // per-tile partial sums of the fused pose head
+    size_t pose_tiles_floats = 0;
+    bool cnv7_valid = true;
     Variant v{};
     int impl = 0;
     int precision = 1;                         // 0 = FP32 MFMA (bit-exact fmaf chains), 1 = f16x3 split (default)
@@ -773,7 +778,8 @@ std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile)
 
 // f16x3 launch of conv layer li: x and y are split-fp16 blocked tensors (y float32 when y_f32)
 int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int Win, void* y, int y_ld,
-                      bool y_f32, int NB) {
+                      bool y_f32, int NB, bool fuse_pose = false, int* pose_bm = nullptr, int* pose_mt = nullptr,
+                      int* pose_ntn = nullptr) {
     const ConvLayer& L = c->L[li];
     ConvParamsH p{};
     int Ho, Wo, pt, pl;
@@ -794,7 +800,33 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         p.g_w = (long)L.npad_h * p.w_row_bytes; p.g_bias = L.npad_h;
     }
     if (const char* e = getenv("DAVO_DBG")) p.dbg = atoi(e);
-    const std::vector<LaunchH> plan = plan_layer_h3(p.M, L.npad_h, L.groups, L.tile_h);
+    std::vector<LaunchH> plan = plan_layer_h3(p.M, L.npad_h, L.groups, L.tile_h);
+    if (fuse_pose) {      // one launch, one tile shape no taller than an image, so a tile touches <= 2 images
+        const int P = Ho * Wo;
+        int best = -1; double bc = 1e30;
+        for (const TileInfo& t : kTiles) {
+            const TileShape ts = tile_shape(t.id);
+            if (ts.bn > L.npad_h || L.npad_h % ts.bn || ts.bm > P) continue;
+            const double cst = h3_cost(t, (long)((p.M + ts.bm - 1) / ts.bm) * (L.npad_h / ts.bn) * L.groups);
+            if (cst < bc) { bc = cst; best = t.id; }
+        }
+        if (best < 0) return fail(c, DAVO_ERR_INVALID, "no tile fits the fused pose head");
+        plan = {{0, p.M, best}};
+        const TileShape ts = tile_shape(best);
+        const int mt = (p.M + ts.bm - 1) / ts.bm, ntn = L.npad_h / ts.bn;
+        const size_t need = (size_t)L.groups * mt * ntn * 6;
+        if (need > c->pose_tiles_floats) {
+            if (c->d_pose_tiles) { int rs = sync_all_slots(c); if (rs) return rs; HIP_TRY(c, hipFree(c->d_pose_tiles)); c->d_pose_tiles = nullptr; }
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_pose_tiles), need * sizeof(float) * 4));   // x4: one region per in-flight slot
+            c->pose_tiles_floats = need;
+        }
+        const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;      // the slot this batch runs in
+        p.y_mode = 2; p.pose_w = c->d_wpred; p.pose_partial = c->d_pose_tiles + (size_t)slot_idx * c->pose_tiles_floats;
+        p.pose_P = P; p.pose_mt = mt;
+        if (pose_bm) *pose_bm = ts.bm;
+        if (pose_mt) *pose_mt = mt;
+        if (pose_ntn) *pose_ntn = ntn;
+    }
     c->last_plan[li][0] = c->last_plan[li][1] = 0;
     for (size_t i = 0; i < plan.size() && i < 2; ++i) {
         const TileShape ts = tile_shape(plan[i].tile);
@@ -900,7 +932,8 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     // f16x3, DAVO_FUSE_PACK=1: cnv1 builds its input patch straight from the raw inputs (mask + pack fused in,
     // the packed tensor never touches HBM).  Measured equal in time to mask_pack + cnv1 (the fused fill is bound
     // by its byte loads), so the two-kernel form stays the default.
-    static const bool fuse_env = getenv("DAVO_FUSE_PACK") && atoi(getenv("DAVO_FUSE_PACK")) == 1;
+    static const bool fuse_env_default = getenv("DAVO_FUSE_PACK") && atoi(getenv("DAVO_FUSE_PACK")) == 1;
+    const bool fuse_env = fuse_env_default || c->opt_fuse_pack;
     static const bool patch1 = !(getenv("DAVO_CNV1_PATCH") && atoi(getenv("DAVO_CNV1_PATCH")) == 0);
     const bool fused = h3 && patch1 && fuse_env;
     c->packed_valid = !fused;
@@ -926,6 +959,9 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     const int c6 = v.cnv6_out;
     float** a = c->d_act;
     int rc;
+    bool pose_fused = false;
+    int pose_bm = 0, pose_mt = 0, pose_ntn = 0;
+    c->cnv7_valid = true;
     if (h3) {
         if (patch1) { if ((rc = run_cnv1_patch(c, fused, d_img, d_flow, d_seg, a[0], NB))) return rc; }
         else if ((rc = run_conv_layer_h3(c, 0, c->d_packed, 8, H, W, a[0], 16, false, NB))) return rc;
@@ -934,7 +970,9 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         if ((rc = run_conv_layer_h3(c, 3, a[2], 64, c->H2, c->W2, a[3], 128, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 4, a[3], 128, c->H2, c->W2, a[4], 256, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 5, a[4], 256, c->H2, c->W2, a[5], 2 * c6, false, NB))) return rc;
-        if ((rc = run_conv_layer_h3(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, true, NB))) return rc;
+        pose_fused = c->opt_fuse_pose && c->H3 * c->W3 >= 128;
+        if ((rc = run_conv_layer_h3(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, true, NB, pose_fused, &pose_bm, &pose_mt, &pose_ntn))) return rc;
+        c->cnv7_valid = !pose_fused;
     } else if (c->impl == 0) {
         if ((rc = run_conv_layer(c, 0, c->d_packed, 8, H, W, a[0], 16, NB))) return rc;
         if ((rc = run_conv_layer(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, NB))) return rc;
@@ -959,7 +997,14 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
             if ((rc = run_direct(c, "cnv7", a[5], NB, c->H2, c->W2, c6, 2 * c6, h * c6, hp + "cnv7/weights", hp + "cnv7/biases", 3, 256, 2, 1, a[6], 512, h * 256))) return rc;
         }
     }
-    {
+    if (pose_fused) {
+        ProfScope ps(c, "pose_head");
+        const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;
+        hipLaunchKernelGGL(pose_from_tiles, dim3((NB * 6 + 63) / 64), dim3(64), 0, s,
+                           c->d_pose_tiles + (size_t)slot_idx * c->pose_tiles_floats, NB, c->H3 * c->W3, pose_bm, pose_mt,
+                           pose_ntn, c->d_bpred, static_cast<float*>(d_pose));
+        HIP_TRY(c, hipGetLastError());
+    } else {
         ProfScope ps(c, "pose_head");
         hipLaunchKernelGGL(pose_head_partial, dim3(PH_SPLIT, NB, 2), dim3(256), 0, s, a[6], c->H3 * c->W3, c->d_wpred,
                            c->d_pose_partial);
@@ -1147,7 +1192,7 @@ void davo_destroy(davo_ctx* c) {
         if (L.d_wh) (void)hipFree(L.d_wh);
         if (L.d_bh) (void)hipFree(L.d_bh);
     }
-    void* misc[] = {c->d_w1patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
+    void* misc[] = {c->d_pose_tiles, c->d_w1patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
     for (auto& pe : c->prof_entries)
         for (auto& ab : pe.pending) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
@@ -1244,6 +1289,15 @@ int davo_set_inflight(davo_ctx* c, int n) {
     return DAVO_OK;
 }
 
+int davo_set_option(davo_ctx* c, const char* key, int value) {
+    if (!c || !key) return DAVO_ERR_INVALID;
+    const std::string k = key;
+    if (k == "fuse_pose") c->opt_fuse_pose = value != 0;
+    else if (k == "fuse_pack") c->opt_fuse_pack = value != 0;
+    else return fail(c, DAVO_ERR_INVALID, "unknown option `%s'", key);
+    return DAVO_OK;
+}
+
 int davo_set_precision(davo_ctx* c, int precision) {
     if (!c || (precision != 0 && precision != 1)) return fail(c, DAVO_ERR_INVALID, "precision must be 0 (f32) or 1 (f16x3)");
     c->precision = precision;
@@ -1280,6 +1334,8 @@ int davo_debug_read(davo_ctx* c, const char* tensor, float* host_out, size_t n_f
         for (int i = 0; i < 7; ++i)
             if (t == names[i]) { src = c->d_act[i]; n = NB * c->act_floats_per_img[i]; }
     }
+    if (t == "cnv7" && !c->cnv7_valid)
+        return fail(c, DAVO_ERR_NOT_READY, "cnv7 was not materialised: the pose head ran fused (davo_set_option(ctx, \"fuse_pose\", 0))");
     if (!src) return fail(c, DAVO_ERR_INVALID, "unknown tensor `%s'", tensor);
     if (n != n_floats) return fail(c, DAVO_ERR_INVALID, "`%s' holds %zu floats, caller asked for %zu", tensor, n, n_floats);
     int rc = davo_memcpy_d2h(c, host_out, src, n * sizeof(float));

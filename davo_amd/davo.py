@@ -115,6 +115,10 @@ class Engine:
     def synchronize(self):
         self._check(self._L.davo_synchronize(self._ctx))
 
+    def set_option(self, key, value):
+        """'fuse_pose' (default 1), 'fuse_pack' (default 0): see include/davo_hip.h."""
+        self._check(self._L.davo_set_option(self._ctx, key.encode(), int(value)))
+
     def set_inflight(self, n):
         """Batches kept in flight by forward_device (1..4): n streams + n workspaces, rotated per call."""
         self._check(self._L.davo_set_inflight(self._ctx, int(n)))

@@ -121,6 +121,12 @@ int davo_last_plan(davo_ctx* ctx, int layer, int launch, int* mtiles, int* bn);
  *   0 "f32": v_mfma_f32_32x32x2_f32, bit-for-bit float32 fmaf chains, no range restriction. */
 int davo_set_precision(davo_ctx* ctx, int precision);
 
+/* Kernel-fusion switches of the f16x3 path (both modes give the same poses to ~1e-7):
+ *   "fuse_pose" (default 1): pred 1x1 + spatial mean + 0.01 (nets/posenn.py:240-250) run in cnv7's
+ *       epilogue; the cnv7 activation is never written to HBM.  0 = cnv7 stored, separate pose-head kernels.
+ *   "fuse_pack" (default 0): cnv1 builds its input patch from the raw inputs (mask + pack fused in). */
+int davo_set_option(davo_ctx* ctx, const char* key, int value);
+
 /* ---- test hooks -------------------------------------------------------------------------
  * impl 0 = MFMA implicit-GEMM kernels (default, the product path);
  * impl 1 = one-thread-per-output direct convolution in HIP on the reference's own tensor
