@@ -187,28 +187,27 @@ void conv_igemm_h3(ConvParamsH p) {
     }
     int dma_cblk = 0, dma_tq = 0;
     // one 32-k chunk = two K=16 MFMA steps; per step and output tile: hi*hi, hi*lo, lo*hi
-#define H3_COMPUTE(buf_)                                                                           \
+#define H3_STEP(buf_, s_)                                                                          \
     {                                                                                              \
         const uint8_t* a = As + (buf_) * BMH * ROWB + (wm * TM * 32 + li) * ROWB;                  \
         const uint8_t* b = Bs + (buf_) * BNH * ROWB + (wn * TN * 32 + li) * ROWB;                  \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                            \
-            half8 ah[TM], al[TM], bh[TN], bl[TN];                                                  \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                       \
-                ah[i] = lds_frag(a + i * 32 * ROWB + foff[0][s]);                                  \
-                al[i] = lds_frag(a + i * 32 * ROWB + foff[1][s]);                                  \
-            }                                                                                      \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
-                bh[j] = lds_frag(b + j * 32 * ROWB + foff[0][s]);                                  \
-                bl[j] = lds_frag(b + j * 32 * ROWB + foff[1][s]);                                  \
-            }                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
-                }                                                                                  \
+        half8 ah[TM], al[TM], bh[TN], bl[TN];                                                      \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                           \
+            ah[i] = lds_frag(a + i * 32 * ROWB + foff[0][s_]);                                     \
+            al[i] = lds_frag(a + i * 32 * ROWB + foff[1][s_]);                                     \
         }                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                           \
+            bh[j] = lds_frag(b + j * 32 * ROWB + foff[0][s_]);                                     \
+            bl[j] = lds_frag(b + j * 32 * ROWB + foff[1][s_]);                                     \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+            }                                                                                      \
     }
+#define H3_COMPUTE(buf_) { H3_STEP(buf_, 0) H3_STEP(buf_, 1) }
 
     // fragment byte offsets inside an LDS row for (plane, k-step): logical unit plane*4 + 2s + lh,
     // XOR-swizzled with (row>>1)&7 = (li>>1)&7 in the DMA layout (tile row bases are multiples of 32)
@@ -259,8 +258,16 @@ void conv_igemm_h3(ConvParamsH p) {
         for (int q = 0; q < p.nchunks; ++q) {
             const int nslot = slot == 0 ? NST - 1 : slot - 1; // (q + NST - 1) % NST
             const bool more = q + NST - 1 < p.nchunks;
-            if (more && !(p.dbg & 1)) H3_DMA_CHUNK(q + NST - 1, nslot)
-            if (!(p.dbg & 2)) H3_COMPUTE(slot)
+            // Stagger: the two waves that share a SIMD (w and w+4 of an 8-wave workgroup) would otherwise run
+            // the same phases in lockstep — both computing DMA addresses while the matrix pipe idles, then both
+            // queueing MFMAs.  The second half of the workgroup issues its DMA after its first k-step instead
+            // of before it, which offsets the partners by one address phase at no cost in synchronisation
+            // (the DMA only has to be issued somewhere inside the iteration).
+            const bool late_dma = (p.dbg & 4) ? false : (WM * WN >= 8 && wave_u >= (WM * WN) / 2);
+            if (more && !late_dma && !(p.dbg & 1)) H3_DMA_CHUNK(q + NST - 1, nslot)
+            if (!(p.dbg & 2)) H3_STEP(slot, 0)
+            if (more && late_dma && !(p.dbg & 1)) H3_DMA_CHUNK(q + NST - 1, nslot)
+            if (!(p.dbg & 2)) H3_STEP(slot, 1)
             if (q + 1 < p.nchunks) {
                 if (NST == 3 && more) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
                 else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
@@ -359,5 +366,6 @@ void conv_igemm_h3(ConvParamsH p) {
 #undef H3_DMA_B
 #undef H3_DMA_CHUNK
 #undef H3_COMPUTE
+#undef H3_STEP
 
 }  // namespace davo
