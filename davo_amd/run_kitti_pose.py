@@ -40,14 +40,20 @@ def main(argv=None):
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    device = None
+    device, device_index = None, local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("DAVO_DIST_BACKEND", "nccl")            # "nccl" is RCCL on ROCm; "gloo" for rehearsals
+        if os.environ.get("DAVO_SHARE_GPU") == "1":                       # several ranks on one card (1-GPU box rehearsal)
+            device_index = local_rank % max(1, torch.cuda.device_count())
+        if backend == "nccl":
+            torch.cuda.set_device(device_index)
+            device = torch.device("cuda", device_index)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     H, W = a.img_height, a.img_width
     if a.synthetic:
@@ -63,7 +69,7 @@ def main(argv=None):
         from .tf_checkpoint import load_weights
         weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
 
-    system = DAVO(version=a.version, device=local_rank)
+    system = DAVO(version=a.version, device=device_index)
     system.load_weights(weights)
     system.setup_inference(H, W, "davo", a.seq_length, a.batch_size)
     infer = lambda img, flow, seg: system.inference(None, "pose", inputs=(img, flow, seg))["pose"]   # noqa: E731
