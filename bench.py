@@ -262,8 +262,8 @@ def main():
             # matrix-pipe roofline of this algorithm is the fp16 dense peak / 3
             peak, dtype = PEAK_F16_MFMA_TFLOPS / 3.0, "f16x3 (fp16 hi/lo split operands, 3 MFMA products, f32 accumulate)"
             tiles = {0: "128x32", 1: "256x64", 2: "256x128", 3: "128x256", 4: "128x128", 5: "256x256"}
-            kname = ("davo::conv_igemm_h3<3,1,...,6,true,false> (cnv6 main launch: rotation|translation fused, N=256, "
-                     "K=2304, %s tile, LDS-DMA staged)" % tiles.get(plan6[0][1], "?"))
+            kname = ("davo::conv_igemm_h3<3,1,...,6,true,false,true> (cnv6 main launch: rotation|translation fused, N=256, "
+                     "K=2304, %s tile, LDS-DMA staged, v_mfma_f32_16x16x32_f16)" % tiles.get(plan6[0][1], "?"))
             peak_note = "fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP; frac = matrix-pipe utilisation"
         # HBM traffic of the dominant kernel: from the most recent committed PMC pass (profiles/), not live —
         # rocprofv3 counter collection cannot run inside the timed process
@@ -271,7 +271,7 @@ def main():
         try:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-            key = "conv_igemm_f32<3, 1, 128, 6>" if args.precision == "f32" else "conv_igemm_h3<3, 1, 4, 2, 2, 4, 6, true, false>"
+            key = "conv_igemm_f32<3, 1, 128, 6>" if args.precision == "f32" else "conv_igemm_h3<3, 1, 4, 2, 2, 4, 6, true, false"
             for f in reversed(cands):
                 tj = json.load(open(f))
                 hit = [v for k, v in tj["kernels"].items() if key in k]

@@ -35,6 +35,7 @@
 namespace davo {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvParamsH {
     const uint8_t* x;       // split-fp16 blocked activation
@@ -97,7 +98,10 @@ typedef __attribute__((address_space(3))) void lptr_t;
 // SMALLC: Cin < 32, a chunk spans several taps, so the tap (and its bounds test) differs per lane.
 // With Cin >= 32 the tap is uniform over the workgroup and everything about a chunk except the
 // image-bounds test is scalar: the loop then costs ~20 VALU instructions per 24 MFMAs.
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC>
+// M16: use v_mfma_f32_16x16x32_f16 (K = 32 = the whole chunk per instruction) instead of 32x32x16.  Same LDS
+// bytes and matrix cycles per chunk; under matrix-dense load the chip holds a higher clock on the 16x16 shape
+// (MI355X_MICROARCH.md, DVFS give-back item 7), so the faster one is chosen by measurement.
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC, bool M16 = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 2)
 void conv_igemm_h3(ConvParamsH p) {
     using T = TileH<WM, WN, TM, TN>;
@@ -187,7 +191,7 @@ void conv_igemm_h3(ConvParamsH p) {
     }
     int dma_cblk = 0, dma_tq = 0;
     // one 32-k chunk = two K=16 MFMA steps; per step and output tile: hi*hi, hi*lo, lo*hi
-#define H3_STEP(buf_, s_)                                                                          \
+#define H3_STEP32(buf_, s_)                                                                        \
     {                                                                                              \
         const uint8_t* a = As + (buf_) * BMH * ROWB + (wm * TM * 32 + li) * ROWB;                  \
         const uint8_t* b = Bs + (buf_) * BNH * ROWB + (wn * TN * 32 + li) * ROWB;                  \
@@ -207,6 +211,35 @@ void conv_igemm_h3(ConvParamsH p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
             }                                                                                      \
     }
+    // 16x16x32 form: "step" s_ is the N half of the wave tile; the A fragments (whole chunk depth) are read
+    // in step 0 and reused in step 1
+#define H3_STEP16(buf_, s_)                                                                        \
+    {                                                                                              \
+        const uint8_t* a = As + (buf_) * BMH * ROWB + (wm * TM * 32 + l16) * ROWB;                 \
+        const uint8_t* b = Bs + (buf_) * BNH * ROWB + (wn * TN * 32 + (s_) * TN * 16 + l16) * ROWB; \
+        if ((s_) == 0) {                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 2 * TM; ++i) {                                   \
+                a16h[i] = lds_frag(a + i * 16 * ROWB + foff16[0]);                                 \
+                a16l[i] = lds_frag(a + i * 16 * ROWB + foff16[1]);                                 \
+            }                                                                                      \
+        }                                                                                          \
+        half8 bh[TN], bl[TN];                                                                      \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                           \
+            bh[j] = lds_frag(b + j * 16 * ROWB + foff16[0]);                                       \
+            bl[j] = lds_frag(b + j * 16 * ROWB + foff16[1]);                                       \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2 * TM; ++i)                                         \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+                f32x4& c_ = acc16[i][(s_) * TN + j];                                               \
+                c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16h[i], bh[j], c_, 0, 0, 0);          \
+                c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16h[i], bl[j], c_, 0, 0, 0);          \
+                c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16l[i], bh[j], c_, 0, 0, 0);          \
+            }                                                                                      \
+    }
+#define H3_STEP(buf_, s_)                                                                          \
+    {                                                                                              \
+        if constexpr (M16) H3_STEP16(buf_, s_) else H3_STEP32(buf_, s_)                            \
+    }
 #define H3_COMPUTE(buf_) { H3_STEP(buf_, 0) H3_STEP(buf_, 1) }
 
     // fragment byte offsets inside an LDS row for (plane, k-step): logical unit plane*4 + 2s + lh,
@@ -220,10 +253,29 @@ void conv_igemm_h3(ConvParamsH p) {
             foff[pl][s] = (DMA ? (unit ^ ((li >> 1) & 7)) : unit) * 16;
         }
 
+    // 16x16x32 operand map: lane l holds row/col l&15, k-elements 8*(l>>4).. of the 32-chunk = logical unit
+    // plane*4 + (l>>4), swizzled with (row>>1)&7 = ((l&15)>>1)&7 (16-row tile bases are multiples of 16)
+    const int l16 = lane & 15, q16 = lane >> 4;
+    int foff16[2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) foff16[pl] = ((pl * 4 + q16) ^ ((l16 >> 1) & 7)) * 16;
+    half8 a16h[2 * TM], a16l[2 * TM];
+    f32x4 acc16[2 * TM][2 * TN];
+
     // accumulators start at bias / out_scale (exact: out_scale is a power of two) so the epilogue
     // issues no load (see conv_igemm.h)
     f32x16 acc[TM][TN];
-    {
+    if constexpr (M16) {
+        const float inv = 1.0f / p.out_scale;
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) {
+            const float bv = bg[wn * TN * 32 + j * 16 + l16] * inv;
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc16[i][j][r] = bv;
+        }
+    } else {
         const float inv = 1.0f / p.out_scale;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -277,7 +329,17 @@ void conv_igemm_h3(ConvParamsH p) {
         }
     }
 
-    // ---- epilogue, pose head fused (y_mode 2): pred is 1x1 linear and the spatial mean is linear
+    // ---- epilogues.  Both accumulator layouts are walked through the same three helpers:
+    //   column group jj -> column inside the wave tile; (row group ii, register r) -> row inside the wave tile
+    constexpr int NCG = M16 ? 2 * TN : TN, NRG = M16 ? 2 * TM : TM, NREG = M16 ? 4 : 16;
+    auto col_of = [&](int jj) { return M16 ? jj * 16 + l16 : jj * 32 + li; };
+    auto row_of = [&](int ii, int r) { return M16 ? ii * 16 + 4 * q16 + r : ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh; };
+    auto val_of = [&](int ii, int jj, int r) -> float {
+        if constexpr (M16) return acc16[ii][jj][r];
+        else return acc[ii][jj][r];
+    };
+
+    // pose head fused (y_mode 2): pred is 1x1 linear and the spatial mean is linear
     // (nets/posenn.py:240-241), so a tile only has to deliver sum_rows sum_cols relu(x) * Wpred[col][k],
     // split by image.  Fixed summation order -> bitwise reproducible; pose_from_tiles adds the tiles.
     if (p.y_mode == 2) {
@@ -286,17 +348,17 @@ void conv_igemm_h3(ConvParamsH p) {
         const int split_row = (img0 + 1) * p.pose_P - row0;          // tile rows >= split_row: next image
         float q[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = ntile * BNH + wn * TN * 32 + j * 32 + li;
+        for (int jj = 0; jj < NCG; ++jj) {
+            const int n = ntile * BNH + wn * TN * 32 + col_of(jj);
             const float* wp = p.pose_w + ((long)grp * p.Cout + (n < p.Cout ? n : 0)) * 3;
             const float w0 = n < p.Cout ? wp[0] : 0.f, w1 = n < p.Cout ? wp[1] : 0.f, w2 = n < p.Cout ? wp[2] : 0.f;
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int ii = 0; ii < NRG; ++ii)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float v = fmaxf(acc[i][j][r] * p.out_scale, 0.f);
+                for (int r = 0; r < NREG; ++r) {
+                    const int row = wm * TM * 32 + row_of(ii, r);
+                    float v = fmaxf(val_of(ii, jj, r) * p.out_scale, 0.f);
                     if (row0 + row >= p.M) v = 0.f;
                     if (row < split_row) s0 += v; else s1 += v;
                 }
@@ -321,23 +383,21 @@ void conv_igemm_h3(ConvParamsH p) {
         return;
     }
 
-    // ---- epilogue: combine, bias, ReLU; store float32 or re-split for the next layer ---------
+    // combine, bias (already in the accumulator), ReLU; store float32 or re-split for the next layer
     const int ocb_log2 = p.y_ld >= 32 ? 5 : (p.y_ld == 16 ? 4 : 3);
     const int ocb = 1 << ocb_log2;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int ncol = wn * TN * 32 + j * 32 + li;
-        const int n = ntile * BNH + ncol;
+    for (int jj = 0; jj < NCG; ++jj) {
+        const int n = ntile * BNH + wn * TN * 32 + col_of(jj);
         const bool n_ok = n < p.Cout;
         const int ng = p.y_coff + grp * p.g_y_coff + n;              // channel in the output tensor
         const long cbyte = (long)(ng >> ocb_log2) * (ocb * 4) + (ng & (ocb - 1)) * 2;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int ii = 0; ii < NRG; ++ii)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int m = mtile * BMH + row;
-                float v = acc[i][j][r] * p.out_scale;
+            for (int r = 0; r < NREG; ++r) {
+                const int m = mtile * BMH + wm * TM * 32 + row_of(ii, r);
+                float v = val_of(ii, jj, r) * p.out_scale;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (n_ok && m < p.M) {
                     if (p.y_mode == 0) {
@@ -367,5 +427,7 @@ void conv_igemm_h3(ConvParamsH p) {
 #undef H3_DMA_CHUNK
 #undef H3_COMPUTE
 #undef H3_STEP
+#undef H3_STEP16
+#undef H3_STEP32
 
 }  // namespace davo

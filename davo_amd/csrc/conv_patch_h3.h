@@ -25,7 +25,6 @@
 
 namespace davo {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace cp1 {
 constexpr int KS = 7, TH = 8, TW = 16;                 // filter, output tile

@@ -294,11 +294,19 @@ TileShape tile_shape(int t) {
 }
 
 // All f16x3 launches are LDS-DMA staged.  SMALLC (Cin < 32) is a property of the layer.
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool SMALLC>
-hipError_t launch_h3_c(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+// v_mfma 16x16x32 instead of 32x32x16 for the large tiles (higher held clock under matrix-dense load);
+// DAVO_H3_M16=0 selects the 32x32x16 form (A/B measurements)
+bool h3_use_m16() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DAVO_H3_M16"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool SMALLC, bool M16>
+hipError_t launch_h3_m(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
     using T = TileH<WM, WN, TM, TN>;
-    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, true, SMALLC>;
+    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, true, SMALLC, M16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES_DMA);
@@ -307,6 +315,17 @@ hipError_t launch_h3_c(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(T::THREADS), T::LDS_BYTES_DMA, s, p);
     return hipGetLastError();
+}
+
+// All f16x3 launches are LDS-DMA staged.  SMALLC (Cin < 32) is a property of the layer.  The 16x16x32
+// form is used for EVERY tile shape of cnv3..cnv7, so that an output element is summed in the same order
+// whatever tile the launch plan gives it (batch-size invariance to the bit).
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool SMALLC>
+hipError_t launch_h3_c(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    if constexpr (LAYER >= 3 && !SMALLC) {
+        if (h3_use_m16()) return launch_h3_m<KS, STRIDE, WM, WN, TM, TN, LAYER, SMALLC, true>(p, grid, s);
+    }
+    return launch_h3_m<KS, STRIDE, WM, WN, TM, TN, LAYER, SMALLC, false>(p, grid, s);
 }
 
 // MAXBN bounds the instantiations to the N tiles a layer can use (its padded Cout)
