@@ -752,14 +752,18 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
 // smaller tile that again fills whole rounds.  Costs are in units of one round of 256x256 tiles;
 // eff = measured throughput of the tile relative to 256x256 on the K >= 1152 layers.
 struct TileInfo { int id, per_cu; double eff; };
-const TileInfo kTiles[] = {{TILE_256x256, 1, 1.00}, {TILE_128x256, 1, 0.90}, {TILE_256x128, 1, 0.90},
-                           {TILE_128x128, 2, 0.75}, {TILE_256x64, 1, 0.70}, {TILE_128x32, 3, 0.40}};
+const TileInfo kTiles[] = {{TILE_256x256, 1, 1.00}, {TILE_128x256, 1, 0.83}, {TILE_256x128, 1, 0.88},
+                           {TILE_128x128, 2, 0.90}, {TILE_256x64, 1, 0.62}, {TILE_128x32, 3, 0.40}};
 struct LaunchH { int row0, rows, tile; };
 
+// whole rounds run per_cu workgroups per CU side by side; in the last, partial round a CU holds
+// ceil(rest / 256) of them (the dispatcher spreads a short tail one per CU)
 double h3_cost(const TileInfo& t, long ntiles) {
     const TileShape ts = tile_shape(t.id);
     const long slots = 256L * t.per_cu;
-    return (double)((ntiles + slots - 1) / slots) * t.per_cu * (ts.bm * ts.bn / 65536.0) / t.eff;
+    const double one = (ts.bm * ts.bn / 65536.0) / t.eff;
+    const long full = ntiles / slots, rest = ntiles % slots;
+    return (double)full * t.per_cu * one + (double)((rest + 255) / 256) * one;
 }
 
 std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile) {
