@@ -1102,7 +1102,6 @@ int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const d
     init_layer(c->L[5], "cnv6", 3, 1, 2, 256, 2 * c6, 1);
     init_layer(c->L[6], "cnv7", 3, 2, 1, c6, 256, 2);
 
-    const size_t NB = 2 * (size_t)max_batch;
     const int ch[7] = {16, 32, 64, 128, 256, 2 * c6, 512};
     const size_t px[7] = {(size_t)c->H1 * c->W1, (size_t)c->H2 * c->W2, (size_t)c->H2 * c->W2, (size_t)c->H2 * c->W2,
                           (size_t)c->H2 * c->W2, (size_t)c->H2 * c->W2, (size_t)c->H3 * c->W3};
