@@ -115,21 +115,32 @@ def shard_windows(n_windows, world, rank):
     return lo, min(lo + per, n_windows)
 
 
+def _pad_batch(img, flow, seg, batch_size):
+    n = img.shape[0]
+    if n < batch_size:
+        pad = batch_size - n
+        img = np.concatenate([img, np.repeat(img[-1:], pad, 0)])
+        flow = np.concatenate([flow, np.repeat(flow[-1:], pad, 0)])
+        seg = np.concatenate([seg, np.repeat(seg[-1:], pad, 0)])
+    return img, flow, seg, n
+
+
 def run_shard(infer_fn, load_windows, lo, hi, batch_size):
     """Run windows [lo,hi) in batches; the last batch is padded by repeating its last window
     and the padded outputs are dropped (the reference's complete_batch_size,
     utils/common_utils.py:8-13, would append duplicate poses for B>1; parity is defined on
-    B=1 semantics)."""
+    B=1 semantics).
+
+    ``load_windows`` is either a callable ``(s, e) -> (img, flow, seg)`` or an iterable of
+    ``(s, e, (img, flow, seg))`` in window order (davo_amd.loader.ThreadedWindowLoader: the next
+    batches are decoded while this one is on the GPU)."""
     out = np.zeros((hi - lo, 2, 6), np.float32)
-    for s in range(lo, hi, batch_size):
-        e = min(s + batch_size, hi)
-        img, flow, seg = load_windows(s, e)
-        n = e - s
-        if n < batch_size:
-            pad = batch_size - n
-            img = np.concatenate([img, np.repeat(img[-1:], pad, 0)])
-            flow = np.concatenate([flow, np.repeat(flow[-1:], pad, 0)])
-            seg = np.concatenate([seg, np.repeat(seg[-1:], pad, 0)])
+    if callable(load_windows):
+        batches = ((s, min(s + batch_size, hi), load_windows(s, min(s + batch_size, hi))) for s in range(lo, hi, batch_size))
+    else:
+        batches = iter(load_windows)
+    for s, e, (img, flow, seg) in batches:
+        img, flow, seg, n = _pad_batch(img, flow, seg, batch_size)
         out[s - lo:e - lo] = np.asarray(infer_fn(img, flow, seg))[:n]
     return out
 
@@ -157,31 +168,30 @@ def run_sequence(infer_fn, load_windows, n_frames, batch_size, rank=0, world=1, 
     every rank (the stitch is cheap and sequential; rank 0 writes the file)."""
     n_windows = n_frames - 2
     lo, hi = shard_windows(n_windows, world, rank)
+    if hasattr(load_windows, "for_range"):               # a loader factory: build this rank's prefetching loader
+        load_windows = load_windows.for_range(lo, hi, batch_size)
     local = run_shard(infer_fn, load_windows, lo, hi, batch_size)
     poses = gather_poses(local, n_windows, world, rank, device)
     return stitch_trajectory(poses), poses
 
 
 # ---- on-disk inputs (data_loader.py:241-325; doc/preprocessing.md:50-114) -------------------
-def kitti_window_loader(concat_img_dir, seq, n_frames, H, W):
-    """load_windows(s, e) over the reference's dump: '<seq>/<frame>.jpg' = hstack(src0,tgt,src1)
-    (data/preprocess.py:61-66), '-flownet2.npy' (4,H,W,2) f32, '-seglabel.npy' (3,H,W,1) f32;
-    file naming test_kitti_pose.py:44-49.  Window w has tgt frame w+1."""
-    from PIL import Image
-    d = os.path.join(concat_img_dir, "%.2d" % seq)
+class kitti_window_loader:
+    """Loader factory over the reference's dump (davo_amd/loader.py): ``for_range(lo, hi, B)`` gives the
+    threaded, prefetching batch iterator of a rank's shard; calling it ``(s, e)`` loads one batch inline."""
 
-    def load(s, e):
-        imgs, flows, segs = [], [], []
-        for w in range(s, e):
-            stem = os.path.join(d, "%.6d" % (w + 1))
-            im = np.asarray(Image.open(stem + ".jpg").convert("RGB"), np.uint8)
-            if im.shape != (H, 3 * W, 3):
-                raise ValueError("%s.jpg is %s, expected %s" % (stem, im.shape, (H, 3 * W, 3)))
-            imgs.append(im)
-            flows.append(np.load(stem + "-flownet2.npy").astype(np.float32).reshape(4, H, W, 2))
-            segs.append(np.load(stem + "-seglabel.npy").astype(np.float32).reshape(3, H, W, 1))
-        return np.stack(imgs), np.stack(flows), np.stack(segs)
-    return load
+    def __init__(self, concat_img_dir, seq, n_frames, H, W, workers=4, prefetch=2):
+        self.dir, self.seq, self.n_frames, self.H, self.W = concat_img_dir, seq, n_frames, H, W
+        self.workers, self.prefetch = workers, prefetch
+
+    def for_range(self, lo, hi, batch_size):
+        from .loader import kitti_loader
+        return kitti_loader(self.dir, self.seq, self.H, self.W, lo, hi, batch_size, self.workers, self.prefetch)
+
+    def __call__(self, s, e):
+        from .loader import load_window
+        parts = [load_window(self.dir, self.seq, w + 1, self.H, self.W) for w in range(s, e)]
+        return tuple(np.stack([p[k] for p in parts]) for k in range(3))
 
 
 def synthetic_window_loader(H, W, seed=None):

@@ -249,6 +249,24 @@ def test_sequence_driver_on_gpu(tmp_path, c_oracle):
     assert np.abs(got - np.array(want)).max() < 2e-4
 
 
+def test_cli_from_files_on_disk(tmp_path, c_oracle):
+    """Row f2 end to end: a dump in the reference's on-disk format (jpg strip + flownet2/seglabel npy) and an
+    .npz of the weights -> CLI with the threaded loader -> trajectory == oracle on the same decoded files."""
+    from davo_amd import run_kitti_pose, sequence as S, loader as L
+    dump = str(tmp_path / "dump")
+    L.write_synthetic_dump(dump, 9, 11, 64, 96)
+    cfg = parse_version(FLAGSHIP_VERSION)
+    weights = synth.make_weights(cfg)
+    np.savez(str(tmp_path / "w.npz"), **weights)
+    run_kitti_pose.main(["--concat_img_dir", dump, "--ckpt_file", str(tmp_path / "w.npz"), "--output_dir", str(tmp_path),
+                         "--test_seq", "9", "--batch_size", "4", "--img_height", "64", "--img_width", "96"])
+    got = S.read_kitti_poses(str(tmp_path / "09-pred_kitti_pose.txt"))
+    infer = lambda img, flow, seg: c_oracle.forward(cfg, img, flow, seg, weights)   # noqa: E731
+    want, _ = S.run_sequence(infer, S.kitti_window_loader(dump, 9, 11, 64, 96).__call__, 11, 4)
+    assert got.shape == (11, 4, 4)
+    assert np.abs(got - np.array(want)).max() < 2e-4
+
+
 # ---- BASELINE.json configurations at full size ---------------------------------------------------
 def test_config2_batch32_full_size(c_oracle):
     """configs[1]: B=32, 128x416 — every window against the C oracle (multi-launch plan, remainder tiles)."""

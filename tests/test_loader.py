@@ -1,0 +1,66 @@
+"""Row f2: the reference's on-disk window format and the threaded, prefetching loader."""
+import os
+
+import numpy as np
+import pytest
+
+from davo_amd import loader as L
+from davo_amd import sequence as S
+from davo_amd import synth
+
+
+@pytest.fixture(scope="module")
+def dump(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("dump"))
+    assert L.write_synthetic_dump(d, 3, 9, 32, 64) == 7                     # 9 frames -> 7 windows
+    return d
+
+
+def test_dump_layout_and_frame_count(dump):
+    files = sorted(os.listdir(os.path.join(dump, "03")))
+    assert files[0] == "000001-flownet2.npy" and "000001.jpg" in files and "000007-seglabel.npy" in files
+    assert L.count_frames(dump, 3) == 9                                       # #jpg + 2 (test_kitti_pose.py:81-82)
+    img, flow, seg = L.load_window(dump, 3, 1, 32, 64)
+    assert img.shape == (32, 192, 3) and img.dtype == np.uint8
+    assert flow.shape == (4, 32, 64, 2) and seg.shape == (3, 32, 64, 1)
+    _, flow0, seg0 = synth.make_inputs(1, 32, 64, first_window=0)
+    assert np.array_equal(flow, flow0[0]) and np.array_equal(seg, seg0[0])   # npy arrays are exact; jpg is lossy
+    with pytest.raises(ValueError, match="expected"):
+        L.load_window(dump, 3, 1, 32, 65)
+
+
+def test_threaded_loader_order_and_content(dump):
+    ld = L.kitti_loader(dump, 3, 32, 64, 1, 7, batch_size=4, workers=3, prefetch=1)
+    got = list(ld)
+    assert [(s, e) for s, e, _ in got] == [(1, 5), (5, 7)] and len(ld) == 2
+    for s, e, (img, flow, seg) in got:
+        assert img.shape[0] == e - s
+        for k, w in enumerate(range(s, e)):
+            ref = L.load_window(dump, 3, w + 1, 32, 64)
+            assert np.array_equal(img[k], ref[0]) and np.array_equal(flow[k], ref[1]) and np.array_equal(seg[k], ref[2])
+
+
+def test_loader_propagates_errors_and_stops_early(dump):
+    def bad(w):
+        if w == 3:
+            raise IOError("boom %d" % w)
+        return L.load_window(dump, 3, w + 1, 32, 64)
+    it = iter(L.ThreadedWindowLoader(bad, 0, 7, 2, workers=2, prefetch=1))
+    assert next(it)[0] == 0
+    with pytest.raises(IOError, match="boom 3"):
+        for _ in it:
+            pass
+    it2 = iter(L.kitti_loader(dump, 3, 32, 64, 0, 7, 1, workers=2, prefetch=1))
+    next(it2)
+    it2.close()                                                              # consumer gives up: producer must exit
+
+
+def test_run_sequence_with_prefetching_loader_matches_inline(dump, c_oracle):
+    from davo_amd import parse_version, FLAGSHIP_VERSION
+    cfg = parse_version(FLAGSHIP_VERSION)
+    weights = synth.make_weights(cfg)
+    infer = lambda img, flow, seg: c_oracle.forward(cfg, img, flow, seg, weights, nthreads=2)   # noqa: E731
+    fac = S.kitti_window_loader(dump, 3, 9, 32, 64, workers=2, prefetch=2)
+    traj_a, poses_a = S.run_sequence(infer, fac, 9, 3)                       # threaded loader (factory)
+    traj_b, poses_b = S.run_sequence(infer, fac.__call__, 9, 3)              # inline (callable) form
+    assert np.array_equal(poses_a, poses_b) and len(traj_a) == 9
