@@ -17,6 +17,7 @@ EXPORTS = (
     "davo_last_error", "davo_destroy", "davo_device_malloc", "davo_device_free", "davo_memcpy_h2d",
     "davo_memcpy_d2h", "davo_synchronize", "davo_set_stream", "davo_set_inflight", "davo_profile_enable",
     "davo_profile_reset", "davo_profile_entry", "davo_last_plan", "davo_set_option", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
+    "davo_host_alloc", "davo_host_free",
 )
 
 
@@ -68,6 +69,8 @@ def lib():
     L.davo_destroy.restype = None
     L.davo_device_malloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.davo_device_free.argtypes = [vp, vp]
+    L.davo_host_alloc.argtypes = [i, ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.davo_host_free.argtypes = [vp]
     L.davo_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_size_t]
     L.davo_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_size_t]
     L.davo_synchronize.argtypes = [vp]

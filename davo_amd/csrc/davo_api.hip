@@ -116,6 +116,9 @@ struct davo_ctx {
     int last_plan[7][2] = {};                  // per layer, per launch: mtiles*1000 + BN (reported by the bench)
     // host-API staging
     void *s_img = nullptr, *s_flow = nullptr, *s_seg = nullptr, *s_pose = nullptr;
+    hipStream_t copy_stream = nullptr;         // H2D of the next sub-batch runs here while the previous one computes
+    std::vector<hipEvent_t> copy_done;
+    int host_chunk = 8;                        // davo_forward: windows per sub-batch (davo_set_option "host_chunk"; 0 = whole batch)
     // profiling
     bool prof = false;
     bool prof_dominant_only = false;           // profile mode 2: bracket only the main cnv6 launch
@@ -1191,11 +1194,31 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
         HIP_TRY(c, hipMalloc(&c->s_seg, nb_seg * c->max_batch));
         HIP_TRY(c, hipMalloc(&c->s_pose, (size_t)c->max_batch * 12 * sizeof(float)));
     }
-    HIP_TRY(c, hipMemcpyAsync(c->s_img, img, nb_img * B, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->s_flow, flow, nb_flow * B, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->s_seg, seg, nb_seg * B, hipMemcpyHostToDevice, c->stream));
-    int rc = forward_device(c, B, c->s_img, c->s_flow, c->s_seg, c->s_pose);
-    if (rc) return rc;
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    // Sub-batches: the copy of chunk i+1 (copy_stream) overlaps the kernels of chunk i (compute stream).
+    // Results do not depend on the split (windows are independent; tests/test_hip_parity.py batch invariance).
+    // Only flow planes 0 and 1 are read by the path (davo.py:978-982), so only those cross PCIe.
+    const int chunk = (c->host_chunk > 0 && B >= 2 * c->host_chunk) ? c->host_chunk : B;
+    const int nchunks = (B + chunk - 1) / chunk;
+    while ((int)c->copy_done.size() < nchunks) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->copy_done.push_back(e);
+    }
+    for (int i = 0; i < nchunks; ++i) {
+        const int b0 = i * chunk, nb = std::min(chunk, B - b0);
+        uint8_t* di = (uint8_t*)c->s_img + nb_img * b0;
+        uint8_t* df = (uint8_t*)c->s_flow + nb_flow * b0;
+        uint8_t* ds = (uint8_t*)c->s_seg + nb_seg * b0;
+        HIP_TRY(c, hipMemcpyAsync(di, img + nb_img * b0, nb_img * nb, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpy2DAsync(df, nb_flow, (const uint8_t*)flow + nb_flow * b0, nb_flow, nb_flow / 2, nb,
+                                    hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(ds, (const uint8_t*)seg + nb_seg * b0, nb_seg * nb, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(c->copy_done[i], c->copy_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_done[i], 0));
+        int rc = forward_device(c, nb, di, (const float*)df, (const float*)ds, (float*)c->s_pose + (size_t)b0 * 12);
+        if (rc) return rc;
+    }
     HIP_TRY(c, hipMemcpyAsync(pose_out, c->s_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DAVO_OK;
@@ -1214,6 +1237,8 @@ void davo_destroy(davo_ctx* c) {
         if (L.d_wh) (void)hipFree(L.d_wh);
         if (L.d_bh) (void)hipFree(L.d_bh);
     }
+    for (auto e : c->copy_done) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     void* misc[] = {c->d_pose_tiles, c->d_w1patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
     for (auto& pe : c->prof_entries)
@@ -1222,6 +1247,13 @@ void davo_destroy(davo_ctx* c) {
     for (auto& sl : c->slots) free_slot(sl);
     delete c;
 }
+
+int davo_host_alloc(int device, size_t bytes, void** out) {
+    if (!out || bytes == 0) return DAVO_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return DAVO_ERR_HIP;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? DAVO_OK : DAVO_ERR_HIP;
+}
+int davo_host_free(void* p) { return hipHostFree(p) == hipSuccess ? DAVO_OK : DAVO_ERR_HIP; }
 
 int davo_device_malloc(davo_ctx* c, size_t bytes, void** out) {
     if (!c || !out) return DAVO_ERR_INVALID;
@@ -1316,6 +1348,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     const std::string k = key;
     if (k == "fuse_pose") c->opt_fuse_pose = value != 0;
     else if (k == "fuse_pack") c->opt_fuse_pack = value != 0;
+    else if (k == "host_chunk") { if (value < 0) return fail(c, DAVO_ERR_INVALID, "host_chunk must be >= 0"); c->host_chunk = value; }
     else return fail(c, DAVO_ERR_INVALID, "unknown option `%s'", key);
     return DAVO_OK;
 }

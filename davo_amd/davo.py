@@ -22,6 +22,32 @@ class DavoError(RuntimeError):
 _PY_ERR = {-1: ValueError, -2: DavoError, -3: DavoError, -4: MemoryError}
 
 
+class _PinnedBlock:
+    """hipHostMalloc'd block; freed when the last numpy view of it goes away."""
+
+    def __init__(self, device, nbytes):
+        p = ctypes.c_void_p()
+        if _lib.lib().davo_host_alloc(int(device), int(nbytes), ctypes.byref(p)) != 0:
+            raise DavoError("davo_host_alloc(%d bytes) failed on device %d" % (nbytes, device))
+        self.ptr, self.nbytes = p, int(nbytes)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            _lib.lib().davo_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_empty(shape, dtype, device=0):
+    """numpy array over page-locked host memory (include/davo_hip.h: davo_host_alloc): buffers filled by the
+    loader and handed to DAVO.inference / Engine.forward copy at the PCIe DMA rate."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    blk = _PinnedBlock(device, max(n, 1))
+    buf = (ctypes.c_uint8 * blk.nbytes).from_address(blk.ptr.value)
+    buf._owner = blk                                   # the ctypes object is the array's base; it keeps the block alive
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 class DeviceBuffer:
     """A hipMalloc'd buffer owned through a context (bench / multi-GPU shards keep inputs in HBM)."""
 
@@ -116,7 +142,7 @@ class Engine:
         self._check(self._L.davo_synchronize(self._ctx))
 
     def set_option(self, key, value):
-        """'fuse_pose' (default 1), 'fuse_pack' (default 0): see include/davo_hip.h."""
+        """'fuse_pose' (default 1), 'fuse_pack' (default 0), 'host_chunk' (default 8): see include/davo_hip.h."""
         self._check(self._L.davo_set_option(self._ctx, key.encode(), int(value)))
 
     def set_inflight(self, n):

@@ -52,11 +52,16 @@ class ThreadedWindowLoader:
     """Iterate batches of windows [lo, hi) in order; ``workers`` decode threads, ``prefetch`` batches ahead.
 
     ``load_one(w)`` returns the tensors of window w (target frame w + 1).  A failed load is re-raised in
-    the consumer at the position of its batch."""
+    the consumer at the position of its batch.
 
-    def __init__(self, load_one, lo, hi, batch_size, workers=4, prefetch=2):
+    ``alloc(shape, dtype)`` (e.g. ``davo_amd.pinned_empty``) makes the batches live in a ring of
+    ``prefetch + 2`` caller-provided buffer sets (one being filled, ``prefetch`` queued, one with the
+    consumer), so a batch stays valid until the consumer asks for the next one."""
+
+    def __init__(self, load_one, lo, hi, batch_size, workers=4, prefetch=2, alloc=None):
         self.load_one, self.lo, self.hi, self.B = load_one, lo, hi, batch_size
         self.workers, self.prefetch = max(1, workers), max(1, prefetch)
+        self.alloc = alloc
 
     def __len__(self):
         return -(-(self.hi - self.lo) // self.B)
@@ -65,7 +70,10 @@ class ThreadedWindowLoader:
         q = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
 
+        ring, turn = [], 0
+
         def producer():
+            nonlocal turn
             try:
                 with ThreadPoolExecutor(self.workers) as pool:
                     for s in range(self.lo, self.hi, self.B):
@@ -73,7 +81,14 @@ class ThreadedWindowLoader:
                             return
                         e = min(s + self.B, self.hi)
                         parts = list(pool.map(self.load_one, range(s, e)))
-                        batch = tuple(np.stack([p[k] for p in parts]) for k in range(3))
+                        if self.alloc is None:
+                            batch = tuple(np.stack([p[k] for p in parts]) for k in range(3))
+                        else:
+                            if len(ring) < self.prefetch + 2:
+                                ring.append(tuple(self.alloc((self.B,) + parts[0][k].shape, parts[0][k].dtype) for k in range(3)))
+                            bufs = ring[turn % (self.prefetch + 2)]
+                            turn += 1
+                            batch = tuple(np.stack([p[k] for p in parts], out=bufs[k][:e - s]) for k in range(3))
                         q.put((s, e, batch, None))
             except BaseException as exc:            # noqa: BLE001 — hand the failure to the consumer
                 q.put((None, None, None, exc))
@@ -101,9 +116,9 @@ class ThreadedWindowLoader:
                 t.join(timeout=0.05)
 
 
-def kitti_loader(dump_dir, seq, H, W, lo, hi, batch_size, workers=4, prefetch=2):
+def kitti_loader(dump_dir, seq, H, W, lo, hi, batch_size, workers=4, prefetch=2, alloc=None):
     """Windows [lo, hi) of a sequence dump; window w has target frame w + 1."""
-    return ThreadedWindowLoader(lambda w: load_window(dump_dir, seq, w + 1, H, W), lo, hi, batch_size, workers, prefetch)
+    return ThreadedWindowLoader(lambda w: load_window(dump_dir, seq, w + 1, H, W), lo, hi, batch_size, workers, prefetch, alloc)
 
 
 def write_synthetic_dump(dump_dir, seq, n_frames, H, W, seed=None, quality=95):

@@ -65,7 +65,9 @@ def main(argv=None):
         from glob import glob
         d = os.path.join(a.concat_img_dir, "%.2d" % a.test_seq)
         n_frames = len(glob(d + "/*.jpg")) + 2 * int((a.seq_length - 1) / 2)      # test_kitti_pose.py:81-82
-        load = S.kitti_window_loader(a.concat_img_dir, a.test_seq, n_frames, H, W)
+        from .davo import pinned_empty                   # batches are decoded straight into page-locked memory
+        load = S.kitti_window_loader(a.concat_img_dir, a.test_seq, n_frames, H, W,
+                                     alloc=lambda shape, dtype: pinned_empty(shape, dtype, device_index))
         from .tf_checkpoint import load_weights
         weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
 

@@ -84,6 +84,11 @@ void davo_destroy(davo_ctx* ctx);
 /* ---- device memory / stream plumbing for hosts without a HIP binding (ctypes) ---------- */
 int davo_device_malloc(davo_ctx* ctx, size_t bytes, void** out);
 int davo_device_free(davo_ctx* ctx, void* p);
+/* Page-locked host memory for the buffers handed to davo_forward (what tf.data's prefetch-to-pinned
+ * staging does under sess.run, data_loader.py:319-325): H2D then runs as DMA at the PCIe rate and
+ * overlaps the kernels of the previous sub-batch.  Pageable buffers work too, just slower. */
+int davo_host_alloc(int device, size_t bytes, void** out);
+int davo_host_free(void* p);
 int davo_memcpy_h2d(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
 int davo_memcpy_d2h(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
 int davo_synchronize(davo_ctx* ctx);
@@ -124,7 +129,10 @@ int davo_set_precision(davo_ctx* ctx, int precision);
 /* Kernel-fusion switches of the f16x3 path (both modes give the same poses to ~1e-7):
  *   "fuse_pose" (default 1): pred 1x1 + spatial mean + 0.01 (nets/posenn.py:240-250) run in cnv7's
  *       epilogue; the cnv7 activation is never written to HBM.  0 = cnv7 stored, separate pose-head kernels.
- *   "fuse_pack" (default 0): cnv1 builds its input patch from the raw inputs (mask + pack fused in). */
+ *   "fuse_pack" (default 0): cnv1 builds its input patch from the raw inputs (mask + pack fused in).
+ * Host-buffer entry point (davo_forward):
+ *   "host_chunk" (default 8): windows per sub-batch; the H2D copy of sub-batch i+1 overlaps the kernels of
+ *       sub-batch i when B >= 2*host_chunk.  0 = copy the whole batch, then compute.  Results do not change. */
 int davo_set_option(davo_ctx* ctx, const char* key, int value);
 
 /* ---- test hooks -------------------------------------------------------------------------

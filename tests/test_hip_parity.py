@@ -267,6 +267,28 @@ def test_cli_from_files_on_disk(tmp_path, c_oracle):
     assert np.abs(got - np.array(want)).max() < 2e-4
 
 
+def test_host_entry_chunked_copy_and_pinned_buffers():
+    """davo_forward: sub-batch copy/compute overlap (host_chunk), page-locked buffers and the skipped flow
+    planes 2,3 (never read: davo.py:978-982) leave the poses bit-identical."""
+    from davo_amd import pinned_empty
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B = 20                                                    # 8 + 8 + 4: ragged last sub-batch
+    img, flow, seg = synth.make_inputs(B, 64, 96)
+    e = _engine(cfg, 64, 96, B, synth.make_weights(cfg), "f16x3")
+    e.set_option("host_chunk", 0)
+    want = e.forward(img, flow, seg).copy()
+    e.set_option("host_chunk", 8)
+    assert np.array_equal(e.forward(img, flow, seg), want)
+    pin = tuple(pinned_empty(a.shape, a.dtype) for a in (img, flow, seg))
+    for d, a in zip(pin, (img, flow, seg)):
+        d[...] = a
+    pin[1][:, 2:] = np.nan                                    # unused planes must not matter (and are not copied)
+    assert np.array_equal(e.forward(*pin), want)
+    assert np.array_equal(e.forward(pin[0][:5], pin[1][:5], pin[2][:5]), want[:5])
+    e.close()
+    del pin
+
+
 # ---- BASELINE.json configurations at full size ---------------------------------------------------
 def test_config2_batch32_full_size(c_oracle):
     """configs[1]: B=32, 128x416 — every window against the C oracle (multi-launch plan, remainder tiles)."""

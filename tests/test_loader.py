@@ -40,6 +40,25 @@ def test_threaded_loader_order_and_content(dump):
             assert np.array_equal(img[k], ref[0]) and np.array_equal(flow[k], ref[1]) and np.array_equal(seg[k], ref[2])
 
 
+def test_loader_buffer_ring(dump):
+    """alloc=...: batches live in a ring of prefetch+2 caller-provided buffer sets and stay valid until the next one is taken."""
+    made = []
+
+    def alloc(shape, dtype):
+        made.append(np.empty(shape, dtype))
+        return made[-1]
+    ld = L.kitti_loader(dump, 3, 32, 64, 0, 7, batch_size=2, workers=2, prefetch=1, alloc=alloc)
+    for s, e, (img, flow, seg) in ld:
+        held = (img.copy(), flow.copy())
+        import time
+        time.sleep(0.05)                                        # let the producer run ahead
+        assert np.array_equal(img, held[0]) and np.array_equal(flow, held[1])
+        ref = L.load_window(dump, 3, s + 1, 32, 64)
+        assert np.array_equal(img[0], ref[0]) and np.array_equal(seg[0], ref[2]) and img.shape[0] == e - s
+        assert any(np.shares_memory(img, m) for m in made)
+    assert len(made) == 3 * 3                                   # (prefetch + 2) sets x 3 tensors
+
+
 def test_loader_propagates_errors_and_stops_early(dump):
     def bad(w):
         if w == 3:

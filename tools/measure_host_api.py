@@ -15,15 +15,23 @@ B = 32
 cfg = parse_version(FLAGSHIP_VERSION)
 img, flow, seg = synth.make_inputs(8, 128, 416)
 img, flow, seg = np.tile(img, (4, 1, 1, 1)), np.tile(flow, (4, 1, 1, 1, 1)), np.tile(seg, (4, 1, 1, 1, 1))
+from davo_amd import pinned_empty                                     # noqa: E402
+
 e = Engine(cfg, 128, 416, B)
 e.load_weights(synth.make_weights(cfg))
-for _ in range(3):
-    e.forward(img, flow, seg)
-t0 = time.perf_counter()
-n = 20
-for _ in range(n):
-    e.forward(img, flow, seg)
-dt = time.perf_counter() - t0
-mb = (img.nbytes + flow.nbytes + seg.nbytes) / 1e6
-print("davo_forward (host buffers, pageable): %.1f triplets/s, %.3f ms per batch of %d, %.1f MB in per batch -> %.1f GB/s H2D-equivalent"
-      % (B * n / dt, dt / n * 1e3, B, mb, mb * n / dt / 1e3))
+pinned = tuple(pinned_empty(a.shape, a.dtype) for a in (img, flow, seg))
+for d, a in zip(pinned, (img, flow, seg)):
+    d[...] = a
+mb = (img.nbytes + flow.nbytes // 2 + seg.nbytes) / 1e6              # flow planes 2,3 are never read and never copied
+n = 30
+for label, bufs in (("pageable", (img, flow, seg)), ("pinned", pinned)):
+    for chunk in (0, 8):
+        e.set_option("host_chunk", chunk)
+        for _ in range(3):
+            ref = e.forward(*bufs)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            e.forward(*bufs)
+        dt = time.perf_counter() - t0
+        print("davo_forward host buffers %-8s host_chunk=%d: %8.1f triplets/s, %.3f ms per batch of %d, %.1f MB H2D per batch -> %.1f GB/s"
+              % (label, chunk, B * n / dt, dt / n * 1e3, B, mb, mb * n / dt / 1e3), flush=True)
