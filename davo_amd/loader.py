@@ -18,7 +18,7 @@ path is defined from decoded tensors, not from .jpg files.
 import os
 import queue
 import threading
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
 
 import numpy as np
 
@@ -36,9 +36,65 @@ def load_window(dump_dir, seq, tgt_idx, H, W):
         img = np.asarray(im.convert("RGB"), np.uint8)
     if img.shape != (H, 3 * W, 3):
         raise ValueError("%s is %s, expected %s" % (jpg, img.shape, (H, 3 * W, 3)))
-    flow = np.load(flo).astype(np.float32, copy=False).reshape(4, H, W, 2)
-    seg = np.load(sg).astype(np.float32, copy=False).reshape(3, H, W, 1)
+    # memory-mapped: the one copy of these arrays is the worker's write into its slot of the batch buffer
+    flow = np.load(flo, mmap_mode="r").astype(np.float32, copy=False).reshape(4, H, W, 2)
+    seg = np.load(sg, mmap_mode="r").astype(np.float32, copy=False).reshape(3, H, W, 1)
     return img, flow, seg
+
+
+def _read_npy_into(path, dst):
+    """Read a C-ordered .npy of dst's dtype and size straight into dst (no intermediate array); anything else
+    goes through np.load + cast."""
+    with open(path, "rb") as f:
+        major, _ = np.lib.format.read_magic(f)
+        shape, fortran, dtype = (np.lib.format.read_array_header_1_0 if major == 1 else np.lib.format.read_array_header_2_0)(f)
+        if not fortran and dtype == dst.dtype and int(np.prod(shape)) == dst.size and dst.flags.c_contiguous:
+            if f.readinto(memoryview(dst).cast("B")) != dst.nbytes:
+                raise ValueError("%s is truncated" % path)
+            return
+    dst[...] = np.load(path).astype(dst.dtype, copy=False).reshape(dst.shape)
+
+
+def _decode_jpeg(path):
+    """Runs in a decode process: file -> (H, W, raw RGB bytes)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        im = im.convert("RGB")
+        return im.height, im.width, im.tobytes()
+
+
+class JpegDecodePool:
+    """Decode processes for the strips.  This Pillow build keeps the GIL while decoding, so threads alone give
+    one core's worth of JPEG decode; the reference's tf.image.decode_jpeg runs on 4 native threads
+    (data_loader.py:283-288).  Start method "spawn": the parent may already hold a HIP context, which must
+    not be forked."""
+
+    def __init__(self, nprocs):
+        import multiprocessing as mp
+        self.pool = ProcessPoolExecutor(nprocs, mp_context=mp.get_context("spawn"))
+
+    def decode(self, path):
+        h, w, raw = self.pool.submit(_decode_jpeg, path).result()
+        return np.frombuffer(raw, np.uint8).reshape(h, w, 3)
+
+    def close(self):
+        self.pool.shutdown(wait=False, cancel_futures=True)
+
+
+def load_window_into(dump_dir, seq, tgt_idx, H, W, img, flow, seg, decoder=None):
+    """load_window writing into the caller's [H,3W,3] / [4,H,W,2] / [3,H,W,1] slots."""
+    jpg, flo, sg = window_paths(dump_dir, seq, tgt_idx)
+    if decoder is None:
+        from PIL import Image
+        with Image.open(jpg) as im:
+            a = np.asarray(im.convert("RGB"), np.uint8)
+    else:
+        a = decoder.decode(jpg)
+    if a.shape != (H, 3 * W, 3):
+        raise ValueError("%s is %s, expected %s" % (jpg, a.shape, (H, 3 * W, 3)))
+    img[...] = a
+    _read_npy_into(flo, flow)
+    _read_npy_into(sg, seg)
 
 
 def count_frames(dump_dir, seq, seq_length=3):
@@ -54,14 +110,15 @@ class ThreadedWindowLoader:
     ``load_one(w)`` returns the tensors of window w (target frame w + 1).  A failed load is re-raised in
     the consumer at the position of its batch.
 
-    ``alloc(shape, dtype)`` (e.g. ``davo_amd.pinned_empty``) makes the batches live in a ring of
-    ``prefetch + 2`` caller-provided buffer sets (one being filled, ``prefetch`` queued, one with the
-    consumer), so a batch stays valid until the consumer asks for the next one."""
+    Batches live in a ring of ``prefetch + 2`` buffer sets (one being filled, ``prefetch`` queued, one with
+    the consumer): a batch is valid until the consumer asks for the next one — copy it to keep it longer.
+    Each decode thread writes its window straight into its slot of the batch.  ``alloc(shape, dtype)``
+    provides the buffers (default ``np.empty``; ``davo_amd.pinned_empty`` for page-locked memory)."""
 
-    def __init__(self, load_one, lo, hi, batch_size, workers=4, prefetch=2, alloc=None):
+    def __init__(self, load_one, lo, hi, batch_size, workers=4, prefetch=2, alloc=None, load_into=None, on_close=None):
         self.load_one, self.lo, self.hi, self.B = load_one, lo, hi, batch_size
         self.workers, self.prefetch = max(1, workers), max(1, prefetch)
-        self.alloc = alloc
+        self.alloc, self.load_into, self.on_close = alloc, load_into, on_close
 
     def __len__(self):
         return -(-(self.hi - self.lo) // self.B)
@@ -70,26 +127,35 @@ class ThreadedWindowLoader:
         q = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
 
+        nring = self.prefetch + 2
         ring, turn = [], 0
+        alloc = self.alloc or np.empty
+
+        def fill(w, bufs, i, parts=None):              # runs in a pool thread: decode + the single copy into the batch
+            if parts is None and self.load_into is not None:
+                self.load_into(w, bufs[0][i], bufs[1][i], bufs[2][i])
+                return
+            parts = self.load_one(w) if parts is None else parts
+            for k in range(3):
+                bufs[k][i] = parts[k]
 
         def producer():
             nonlocal turn
             try:
                 with ThreadPoolExecutor(self.workers) as pool:
+                    first = self.load_one(self.lo) if self.lo < self.hi else None   # shapes and dtypes of a window
                     for s in range(self.lo, self.hi, self.B):
                         if stop.is_set():
                             return
                         e = min(s + self.B, self.hi)
-                        parts = list(pool.map(self.load_one, range(s, e)))
-                        if self.alloc is None:
-                            batch = tuple(np.stack([p[k] for p in parts]) for k in range(3))
-                        else:
-                            if len(ring) < self.prefetch + 2:
-                                ring.append(tuple(self.alloc((self.B,) + parts[0][k].shape, parts[0][k].dtype) for k in range(3)))
-                            bufs = ring[turn % (self.prefetch + 2)]
-                            turn += 1
-                            batch = tuple(np.stack([p[k] for p in parts], out=bufs[k][:e - s]) for k in range(3))
-                        q.put((s, e, batch, None))
+                        if len(ring) < nring:
+                            ring.append(tuple(alloc((self.B,) + p.shape, p.dtype) for p in first))
+                        bufs = ring[turn % nring]
+                        turn += 1
+                        futs = [pool.submit(fill, w, bufs, w - s, first if w == self.lo else None) for w in range(s, e)]
+                        for f in futs:
+                            f.result()
+                        q.put((s, e, tuple(b[:e - s] for b in bufs), None))
             except BaseException as exc:            # noqa: BLE001 — hand the failure to the consumer
                 q.put((None, None, None, exc))
                 return
@@ -114,11 +180,19 @@ class ThreadedWindowLoader:
                 except queue.Empty:
                     pass
                 t.join(timeout=0.05)
+            if self.on_close is not None:
+                self.on_close()
 
 
-def kitti_loader(dump_dir, seq, H, W, lo, hi, batch_size, workers=4, prefetch=2, alloc=None):
-    """Windows [lo, hi) of a sequence dump; window w has target frame w + 1."""
-    return ThreadedWindowLoader(lambda w: load_window(dump_dir, seq, w + 1, H, W), lo, hi, batch_size, workers, prefetch, alloc)
+def kitti_loader(dump_dir, seq, H, W, lo, hi, batch_size, workers=4, prefetch=2, alloc=None, decode_procs=0):
+    """Windows [lo, hi) of a sequence dump; window w has target frame w + 1.  ``decode_procs`` > 0 decodes the
+    strips in that many processes (the ``workers`` threads then only wait for them and read the .npy files)."""
+    dec = JpegDecodePool(decode_procs) if decode_procs > 0 else None
+    return ThreadedWindowLoader(
+        lambda w: load_window(dump_dir, seq, w + 1, H, W), lo, hi, batch_size,
+        max(workers, 2 * decode_procs), prefetch, alloc,
+        load_into=lambda w, i, f, s: load_window_into(dump_dir, seq, w + 1, H, W, i, f, s, dec),
+        on_close=dec.close if dec else None)
 
 
 def write_synthetic_dump(dump_dir, seq, n_frames, H, W, seed=None, quality=95):

@@ -36,6 +36,8 @@ def main(argv=None):
     ap.add_argument("--ckpt_file", default=None)
     ap.add_argument("--version", default=FLAGSHIP_VERSION)
     ap.add_argument("--synthetic", type=int, default=0, help="frame count of a synthetic sequence")
+    ap.add_argument("--decode_procs", type=int, default=4,
+                    help="JPEG decode processes of the input pipeline (data_loader.py:283-288 uses 4 threads); 0 = decode in the loader threads")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -67,7 +69,8 @@ def main(argv=None):
         n_frames = len(glob(d + "/*.jpg")) + 2 * int((a.seq_length - 1) / 2)      # test_kitti_pose.py:81-82
         from .davo import pinned_empty                   # batches are decoded straight into page-locked memory
         load = S.kitti_window_loader(a.concat_img_dir, a.test_seq, n_frames, H, W,
-                                     alloc=lambda shape, dtype: pinned_empty(shape, dtype, device_index))
+                                     alloc=lambda shape, dtype: pinned_empty(shape, dtype, device_index),
+                                     decode_procs=a.decode_procs)
         from .tf_checkpoint import load_weights
         weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
 

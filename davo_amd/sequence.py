@@ -180,13 +180,13 @@ class kitti_window_loader:
     """Loader factory over the reference's dump (davo_amd/loader.py): ``for_range(lo, hi, B)`` gives the
     threaded, prefetching batch iterator of a rank's shard; calling it ``(s, e)`` loads one batch inline."""
 
-    def __init__(self, concat_img_dir, seq, n_frames, H, W, workers=4, prefetch=2, alloc=None):
+    def __init__(self, concat_img_dir, seq, n_frames, H, W, workers=4, prefetch=2, alloc=None, decode_procs=0):
         self.dir, self.seq, self.n_frames, self.H, self.W = concat_img_dir, seq, n_frames, H, W
-        self.workers, self.prefetch, self.alloc = workers, prefetch, alloc
+        self.workers, self.prefetch, self.alloc, self.decode_procs = workers, prefetch, alloc, decode_procs
 
     def for_range(self, lo, hi, batch_size):
         from .loader import kitti_loader
-        return kitti_loader(self.dir, self.seq, self.H, self.W, lo, hi, batch_size, self.workers, self.prefetch, self.alloc)
+        return kitti_loader(self.dir, self.seq, self.H, self.W, lo, hi, batch_size, self.workers, self.prefetch, self.alloc, self.decode_procs)
 
     def __call__(self, s, e):
         from .loader import load_window

@@ -40,6 +40,30 @@ def test_threaded_loader_order_and_content(dump):
             assert np.array_equal(img[k], ref[0]) and np.array_equal(flow[k], ref[1]) and np.array_equal(seg[k], ref[2])
 
 
+def test_decode_processes_match_inline_decode(dump):
+    got = list(L.kitti_loader(dump, 3, 32, 64, 0, 7, batch_size=3, workers=2, prefetch=1, decode_procs=2))
+    assert [(s, e) for s, e, _ in [(g[0], g[1], None) for g in got]] == [(0, 3), (3, 6), (6, 7)]
+    s, e, (img, flow, seg) = got[-1]
+    ref = L.load_window(dump, 3, 7, 32, 64)
+    assert np.array_equal(img[0], ref[0]) and np.array_equal(flow[0], ref[1]) and np.array_equal(seg[0], ref[2])
+
+
+def test_npy_readinto_and_fallback(tmp_path):
+    a = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    np.save(str(tmp_path / "a.npy"), a)
+    dst = np.empty((2, 3, 4), np.float32)
+    L._read_npy_into(str(tmp_path / "a.npy"), dst)
+    assert np.array_equal(dst, a)
+    np.save(str(tmp_path / "b.npy"), a.astype(np.float64))               # other dtype: np.load + cast
+    dst[...] = 0
+    L._read_npy_into(str(tmp_path / "b.npy"), dst)
+    assert np.array_equal(dst, a)
+    with open(str(tmp_path / "a.npy"), "r+b") as f:
+        f.truncate(130)
+    with pytest.raises(ValueError, match="truncated"):
+        L._read_npy_into(str(tmp_path / "a.npy"), dst)
+
+
 def test_loader_buffer_ring(dump):
     """alloc=...: batches live in a ring of prefetch+2 caller-provided buffer sets and stay valid until the next one is taken."""
     made = []
