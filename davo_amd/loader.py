@@ -15,6 +15,7 @@ come out in window order while the next ones are being decoded, so file IO overl
 JPEG decoders differ by +-1 LSB between libjpeg builds (TF's vs Pillow's), which is why parity of the
 path is defined from decoded tensors, not from .jpg files.
 """
+import collections
 import os
 import queue
 import threading
@@ -110,8 +111,8 @@ class ThreadedWindowLoader:
     ``load_one(w)`` returns the tensors of window w (target frame w + 1).  A failed load is re-raised in
     the consumer at the position of its batch.
 
-    Batches live in a ring of ``prefetch + 2`` buffer sets (one being filled, ``prefetch`` queued, one with
-    the consumer): a batch is valid until the consumer asks for the next one — copy it to keep it longer.
+    Batches live in a ring of ``prefetch + 4`` buffer sets (two being filled, one ready, ``prefetch`` queued,
+    one with the consumer): a batch is valid until the consumer asks for the next one — copy it to keep it longer.
     Each decode thread writes its window straight into its slot of the batch.  ``alloc(shape, dtype)``
     provides the buffers (default ``np.empty``; ``davo_amd.pinned_empty`` for page-locked memory)."""
 
@@ -127,7 +128,8 @@ class ThreadedWindowLoader:
         q = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
 
-        nring = self.prefetch + 2
+        FILL = 2                                       # batches being decoded at once (no idle threads at batch ends)
+        nring = self.prefetch + FILL + 2               # + one waiting in q.put, + one with the consumer
         ring, turn = [], 0
         alloc = self.alloc or np.empty
 
@@ -144,18 +146,29 @@ class ThreadedWindowLoader:
             try:
                 with ThreadPoolExecutor(self.workers) as pool:
                     first = self.load_one(self.lo) if self.lo < self.hi else None   # shapes and dtypes of a window
-                    for s in range(self.lo, self.hi, self.B):
-                        if stop.is_set():
-                            return
-                        e = min(s + self.B, self.hi)
-                        if len(ring) < nring:
-                            ring.append(tuple(alloc((self.B,) + p.shape, p.dtype) for p in first))
-                        bufs = ring[turn % nring]
-                        turn += 1
-                        futs = [pool.submit(fill, w, bufs, w - s, first if w == self.lo else None) for w in range(s, e)]
+                    starts = iter(range(self.lo, self.hi, self.B))
+                    pending = collections.deque()
+                    while True:
+                        while len(pending) < FILL:
+                            s = next(starts, None)
+                            if s is None:
+                                break
+                            e = min(s + self.B, self.hi)
+                            if len(ring) < nring:
+                                ring.append(tuple(alloc((self.B,) + p.shape, p.dtype) for p in first))
+                            bufs = ring[turn % nring]
+                            turn += 1
+                            pending.append((s, e, bufs, [pool.submit(fill, w, bufs, w - s, first if w == self.lo else None)
+                                                         for w in range(s, e)]))
+                        if not pending or stop.is_set():
+                            break
+                        s, e, bufs, futs = pending.popleft()
                         for f in futs:
                             f.result()
                         q.put((s, e, tuple(b[:e - s] for b in bufs), None))
+                    for _, _, _, futs in pending:
+                        for f in futs:
+                            f.cancel()
             except BaseException as exc:            # noqa: BLE001 — hand the failure to the consumer
                 q.put((None, None, None, exc))
                 return

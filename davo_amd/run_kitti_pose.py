@@ -36,8 +36,9 @@ def main(argv=None):
     ap.add_argument("--ckpt_file", default=None)
     ap.add_argument("--version", default=FLAGSHIP_VERSION)
     ap.add_argument("--synthetic", type=int, default=0, help="frame count of a synthetic sequence")
-    ap.add_argument("--decode_procs", type=int, default=4,
-                    help="JPEG decode processes of the input pipeline (data_loader.py:283-288 uses 4 threads); 0 = decode in the loader threads")
+    ap.add_argument("--loader_threads", type=int, default=8, help="decode/read threads of the input pipeline (data_loader.py:283-288 uses 4)")
+    ap.add_argument("--decode_procs", type=int, default=0,
+                    help="extra JPEG decode processes, for Pillow builds that hold the GIL while decoding; 0 = decode in the loader threads")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -70,7 +71,7 @@ def main(argv=None):
         from .davo import pinned_empty                   # batches are decoded straight into page-locked memory
         load = S.kitti_window_loader(a.concat_img_dir, a.test_seq, n_frames, H, W,
                                      alloc=lambda shape, dtype: pinned_empty(shape, dtype, device_index),
-                                     decode_procs=a.decode_procs)
+                                     workers=a.loader_threads, decode_procs=a.decode_procs)
         from .tf_checkpoint import load_weights
         weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
 

@@ -65,7 +65,7 @@ def test_npy_readinto_and_fallback(tmp_path):
 
 
 def test_loader_buffer_ring(dump):
-    """alloc=...: batches live in a ring of prefetch+2 caller-provided buffer sets and stay valid until the next one is taken."""
+    """alloc=...: batches live in a ring of prefetch+4 caller-provided buffer sets and stay valid until the next one is taken."""
     made = []
 
     def alloc(shape, dtype):
@@ -80,7 +80,7 @@ def test_loader_buffer_ring(dump):
         ref = L.load_window(dump, 3, s + 1, 32, 64)
         assert np.array_equal(img[0], ref[0]) and np.array_equal(seg[0], ref[2]) and img.shape[0] == e - s
         assert any(np.shares_memory(img, m) for m in made)
-    assert len(made) == 3 * 3                                   # (prefetch + 2) sets x 3 tensors
+    assert len(made) == 4 * 3                                   # 7 windows = 4 batches < prefetch + 4 sets, x 3 tensors
 
 
 def test_loader_propagates_errors_and_stops_early(dump):

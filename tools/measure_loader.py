@@ -18,7 +18,7 @@ def main():
         t0 = time.perf_counter()
         L.write_synthetic_dump(d, 9, N, H, W)
         print("wrote %d windows in %.1f s" % (N - 2, time.perf_counter() - t0), flush=True)
-        for workers, procs in ((1, 0), (4, 0), (4, 2), (4, 4), (8, 8), (8, 12)):
+        for workers, procs in ((1, 0), (4, 0), (8, 0), (16, 0), (8, 8)):
             t0 = t1 = time.perf_counter()
             n = n1 = 0
             for s, e, _ in L.kitti_loader(d, 9, H, W, 0, N - 2, B, workers=workers, prefetch=2, decode_procs=procs):
@@ -34,7 +34,7 @@ def main():
             for rep in range(2):                                         # second run: page cache warm, context creation still included
                 t0 = time.perf_counter()
                 run_kitti_pose.main(["--concat_img_dir", d, "--ckpt_file", os.path.join(d, "w.npz"), "--output_dir", d,
-                                     "--test_seq", "9", "--batch_size", str(B), "--decode_procs", "8"])
+                                     "--test_seq", "9", "--batch_size", str(B), "--loader_threads", "8"])
                 print("CLI files -> trajectory: %.2f s for %d windows" % (time.perf_counter() - t0, N - 2), flush=True)
 
 
