@@ -36,7 +36,7 @@ def main(argv=None):
     ap.add_argument("--ckpt_file", default=None)
     ap.add_argument("--version", default=FLAGSHIP_VERSION)
     ap.add_argument("--synthetic", type=int, default=0, help="frame count of a synthetic sequence")
-    ap.add_argument("--loader_threads", type=int, default=8, help="decode/read threads of the input pipeline (data_loader.py:283-288 uses 4)")
+    ap.add_argument("--loader_threads", type=int, default=4, help="decode/read threads of the input pipeline (as data_loader.py:283-288; more threads contend on the GIL)")
     ap.add_argument("--decode_procs", type=int, default=0,
                     help="extra JPEG decode processes, for Pillow builds that hold the GIL while decoding; 0 = decode in the loader threads")
     a = ap.parse_args(argv)

@@ -34,7 +34,7 @@ def main():
             for rep in range(2):                                         # second run: page cache warm, context creation still included
                 t0 = time.perf_counter()
                 run_kitti_pose.main(["--concat_img_dir", d, "--ckpt_file", os.path.join(d, "w.npz"), "--output_dir", d,
-                                     "--test_seq", "9", "--batch_size", str(B), "--loader_threads", "8"])
+                                     "--test_seq", "9", "--batch_size", str(B), "--loader_threads", "4"])
                 print("CLI files -> trajectory: %.2f s for %d windows" % (time.perf_counter() - t0, N - 2), flush=True)
 
 
