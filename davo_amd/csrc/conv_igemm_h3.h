@@ -56,7 +56,9 @@ struct ConvParamsH {
     int M, ntaps, ntiles_n, mtile0, relu;
     int g_x_boff, g_y_coff;
     long g_w, g_bias;
-    float out_scale;        // 1 / (power of two the layer's weights were multiplied by)
+    float out_scale;        // 2^(shift_out - shift_in) / (power of two the layer's weights were multiplied by)
+    float bias_scale;       // accumulator init = bias * bias_scale (weight scale * 2^shift_in; a power of two)
+    unsigned* range;        // y_mode 1: atomicMax of the stored (scaled) activations' bit patterns; may be null
     // y_mode 2 (cnv7 only): the pose head is fused into the epilogue, nothing is stored but this tile's
     // contribution to sum_pixels sum_channels relu(cnv7) * Wpred[c][k] for the (at most two) images it touches
     const float* pose_w;    // [groups][256][3] pred kernels
@@ -262,11 +264,11 @@ void conv_igemm_h3(ConvParamsH p) {
     half8 a16h[2 * TM], a16l[2 * TM];
     f32x4 acc16[2 * TM][2 * TN];
 
-    // accumulators start at bias / out_scale (exact: out_scale is a power of two) so the epilogue
-    // issues no load (see conv_igemm.h)
+    // accumulators start at bias * bias_scale (exact: a power of two) so the epilogue issues no load
+    // (see conv_igemm.h)
     f32x16 acc[TM][TN];
     if constexpr (M16) {
-        const float inv = 1.0f / p.out_scale;
+        const float inv = p.bias_scale;
 #pragma unroll
         for (int j = 0; j < 2 * TN; ++j) {
             const float bv = bg[wn * TN * 32 + j * 16 + l16] * inv;
@@ -276,7 +278,7 @@ void conv_igemm_h3(ConvParamsH p) {
                 for (int r = 0; r < 4; ++r) acc16[i][j][r] = bv;
         }
     } else {
-        const float inv = 1.0f / p.out_scale;
+        const float inv = p.bias_scale;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float bv = bg[wn * TN * 32 + j * 32 + li] * inv;
@@ -386,6 +388,7 @@ void conv_igemm_h3(ConvParamsH p) {
     // combine, bias (already in the accumulator), ReLU; store float32 or re-split for the next layer
     const int ocb_log2 = p.y_ld >= 32 ? 5 : (p.y_ld == 16 ? 4 : 3);
     const int ocb = 1 << ocb_log2;
+    float vmax = 0.f;                                                // largest |stored value| of this lane (range monitor)
 #pragma unroll
     for (int jj = 0; jj < NCG; ++jj) {
         const int n = ntile * BNH + wn * TN * 32 + col_of(jj);
@@ -406,6 +409,7 @@ void conv_igemm_h3(ConvParamsH p) {
                         // split, then pair up with the neighbouring lane (= neighbouring channel) so that
                         // every lane issues ONE 4-byte store instead of two 2-byte ones: even lanes store
                         // the hi halves of channels (n, n+1), odd lanes the lo halves of (n-1, n)
+                        vmax = fmaxf(vmax, fabsf(v));
                         v = fminf(fmaxf(v, -65504.f), 65504.f);     // fp16 range; see DESIGN.md
                         const _Float16 hi = (_Float16)v;
                         const _Float16 lo = (_Float16)(v - (float)hi);
@@ -419,6 +423,12 @@ void conv_igemm_h3(ConvParamsH p) {
                     }
                 }
             }
+    }
+    if (p.y_mode == 1 && p.range) {      // non-negative floats order like their bit patterns; inf = overflow
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        // one address for the whole launch: only a wave that would raise the record pays for the atomic
+        if (lane == 0 && __float_as_uint(vmax) > __atomic_load_n(p.range, __ATOMIC_RELAXED)) atomicMax(p.range, __float_as_uint(vmax));
     }
 }
 

@@ -47,6 +47,8 @@ struct ConvPatchParams {
     int H, W, Ho, Wo, pad_t, pad_l;
     int tiles_x, tiles_y, ntiles;
     float out_scale;
+    float bias_scale;           // accumulator init = bias * bias_scale
+    unsigned* range;            // atomicMax of the stored activations' bit patterns (range monitor); may be null
     // FUSED = true: the patch is built from the raw inputs (mask + pack fused in, the packed tensor
     // is never materialised): davo.py:1519-1522 (u8 -> f32), :1115,1178 (LUT attention), :1404-1442
     const uint8_t* img;     // u8 [B][H][3W][3]
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchP
         __builtin_amdgcn_global_load_lds((gptr_t*)(p.w + (size_t)k * 1024 + lane * 16), (lptr_t*)(wl + k * 1024), 16, 0, 0);
 
     const int r = lane & 15, kq = lane >> 4;
-    const float bv = p.bias[r] * (1.0f / p.out_scale);         // C/D layout: col = lane & 15
+    const float bv = p.bias[r] * p.bias_scale;                 // C/D layout: col = lane & 15
     // A fragment address of subtile row oy_l: py = 2*oy_l + ky, px = 2*r + 4*h + kq
     const int a_lane = (kq & 1) * ROWB + (r + (kq >> 1)) * 16;
     const uint8_t* a0 = patch + (2 * (2 * wave) * 2) * ROWB + a_lane;
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchP
     };
 
     int t = blockIdx.x;
+    float vmax = 0.f;
     if (t < p.ntiles) issue_patch(t);
     while (t < p.ntiles) {
         const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
@@ -185,8 +188,9 @@ __global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchP
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ox = ox0 + 4 * kq + i;
-                float v = (sub == 0 ? acc0[i] : acc1[i]) * p.out_scale;
-                v = fminf(fmaxf(v, 0.f), 65504.f);
+                float v = fmaxf((sub == 0 ? acc0[i] : acc1[i]) * p.out_scale, 0.f);
+                if (ox < p.Wo) vmax = fmaxf(vmax, v);
+                v = fminf(v, 65504.f);
                 if (ox < p.Wo) {
                     // even lanes store the hi halves of channels (n, n+1), odd lanes the lo halves of (n-1, n)
                     const _Float16 hi = (_Float16)v;
@@ -202,6 +206,12 @@ __global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchP
             }
         }
         t = tnext;
+    }
+    if (p.range) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        // one address for the whole launch: only a wave that would raise the record pays for the atomic
+        if (lane == 0 && __float_as_uint(vmax) > __atomic_load_n(p.range, __ATOMIC_RELAXED)) atomicMax(p.range, __float_as_uint(vmax));
     }
 }
 

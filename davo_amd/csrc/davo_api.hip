@@ -118,6 +118,10 @@ struct davo_ctx {
     void *s_img = nullptr, *s_flow = nullptr, *s_seg = nullptr, *s_pose = nullptr;
     hipStream_t copy_stream = nullptr;         // H2D of the next sub-batch runs here while the previous one computes
     std::vector<hipEvent_t> copy_done;
+    // f16x3 range management: activations are stored as fp16 pairs scaled by 2^act_shift[layer] (davo_calibrate);
+    // every storing epilogue atomicMax-es the largest stored magnitude into d_range[layer]
+    int act_shift[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned* d_range = nullptr;               // [8]
     int host_chunk = 8;                        // davo_forward: windows per sub-batch (davo_set_option "host_chunk"; 0 = whole batch)
     // profiling
     bool prof = false;
@@ -820,7 +824,12 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
     p.y_mode = y_f32 ? 0 : 1; p.y_ld = y_ld; p.y_coff = 0; p.Cout = L.cout;
     p.pad_t = pt; p.pad_l = pl; p.rate = L.rate;
     p.M = NB * Ho * Wo; p.ntaps = L.KS * L.KS; p.mtile0 = 0; p.relu = 1;
-    p.out_scale = 1.0f / L.wscale;
+    {   // stored activations carry 2^act_shift (exact); cnv7 feeds the float32 pose head unscaled
+        const int sin = li == 0 ? 0 : c->act_shift[li - 1], sout = li == 6 ? 0 : c->act_shift[li];
+        p.out_scale = ldexpf(1.0f / L.wscale, sout - sin);
+        p.bias_scale = ldexpf(L.wscale, sin);
+        p.range = c->d_range ? c->d_range + li : nullptr;
+    }
     if (L.groups == 2) {
         p.g_x_boff = L.cin * 4; p.g_y_coff = L.cout;
         p.g_w = (long)L.npad_h * p.w_row_bytes; p.g_bias = L.npad_h;
@@ -886,7 +895,9 @@ int run_cnv1_patch(davo_ctx* c, bool fused, const void* d_img, const void* d_flo
     p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
     p.H = c->H; p.W = c->W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pt; p.pad_l = pl;
     p.tiles_x = (Wo + cp1::TW - 1) / cp1::TW; p.tiles_y = (Ho + cp1::TH - 1) / cp1::TH;
-    p.out_scale = 1.0f / L.wscale;
+    p.out_scale = ldexpf(1.0f / L.wscale, c->act_shift[0]);
+    p.bias_scale = L.wscale;
+    p.range = c->d_range;
     p.ntiles = NB * p.tiles_x * p.tiles_y;
     p.img = static_cast<const uint8_t*>(d_img); p.flow = static_cast<const float*>(d_flow);
     p.seg = static_cast<const float*>(d_seg); p.tab = c->d_tab; p.v = c->v;
@@ -1118,6 +1129,8 @@ int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const d
     activate_slot(c, 0);
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_zeros), 256));
     HIP_TRY(c, hipMemset(c->d_zeros, 0, 256));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_range), 8 * sizeof(unsigned)));
+    HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned)));
     return DAVO_OK;
 }
 
@@ -1179,6 +1192,25 @@ int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flo
     return rc;
 }
 
+// f16x3 only.  Stored activations (fp16 hi/lo pairs) are float32-grade while the layer's largest stored value is
+// below the fp16 maximum (above it values were clamped) and not so small that the pairs lose their low bits
+// (tools/exp_activation_scale.py: the 1e-4 bar holds down to ~2^-16 of O(1) activations; 2^-11 is the guard).
+static int check_range(davo_ctx* c, const unsigned raw[6]) {
+    static const char* names[6] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6"};
+    for (int i = 0; i < 6; ++i) {
+        float v;
+        memcpy(&v, &raw[i], sizeof v);
+        const float actual = ldexpf(v, -c->act_shift[i]);
+        if (!(v < 65504.f))
+            return fail(c, DAVO_ERR_RANGE, "%s activations reach %.4g: outside the fp16-pair storage range at scale 2^%d "
+                        "(values were clamped) - run davo_calibrate() or davo_set_precision(ctx, 0)", names[i], (double)actual, c->act_shift[i]);
+        if (v > 0.f && v < 0x1p-11f)
+            return fail(c, DAVO_ERR_RANGE, "%s activations are at most %.4g: too small for the fp16-pair storage at scale 2^%d "
+                        "- run davo_calibrate() or davo_set_precision(ctx, 0)", names[i], (double)actual, c->act_shift[i]);
+    }
+    return DAVO_OK;
+}
+
 int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, const float* seg, float* pose_out) {
     if (!c) return DAVO_ERR_INVALID;
     if (!img || !flow || !seg || !pose_out) return fail(c, DAVO_ERR_INVALID, "null host pointer");
@@ -1195,6 +1227,7 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
         HIP_TRY(c, hipMalloc(&c->s_pose, (size_t)c->max_batch * 12 * sizeof(float)));
     }
     if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipMemsetAsync(c->d_range, 0, 8 * sizeof(unsigned), c->stream));      // the monitor covers this call
     // Sub-batches: the copy of chunk i+1 (copy_stream) overlaps the kernels of chunk i (compute stream).
     // Results do not depend on the split (windows are independent; tests/test_hip_parity.py batch invariance).
     // Only flow planes 0 and 1 are read by the path (davo.py:978-982), so only those cross PCIe.
@@ -1220,8 +1253,80 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
         if (rc) return rc;
     }
     HIP_TRY(c, hipMemcpyAsync(pose_out, c->s_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    unsigned raw[6];
+    HIP_TRY(c, hipMemcpyAsync(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return c->last_precision == 1 ? check_range(c, raw) : DAVO_OK;
+}
+
+int davo_activation_range(davo_ctx* c, float* max_abs, int* shifts, int reset) {
+    if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    unsigned raw[6];
+    HIP_TRY(c, hipMemcpy(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) {
+        float v;
+        memcpy(&v, &raw[i], sizeof v);
+        if (max_abs) max_abs[i] = ldexpf(v, -c->act_shift[i]);
+        if (shifts) shifts[i] = c->act_shift[i];
+    }
+    if (reset) HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned)));
     return DAVO_OK;
+}
+
+int davo_set_activation_shifts(davo_ctx* c, const int* shifts) {
+    if (!c) return DAVO_ERR_INVALID;
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    for (int i = 0; i < 6; ++i) {
+        const int s = shifts ? shifts[i] : 0;
+        if (s < -60 || s > 60) return fail(c, DAVO_ERR_INVALID, "activation shift %d outside [-60,60]", s);
+        c->act_shift[i] = s;
+    }
+    return DAVO_OK;
+}
+
+int davo_calibrate(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, int* shifts_out) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
+    if (!d_img || !d_flow || !d_seg) return fail(c, DAVO_ERR_INVALID, "null device pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    activate_slot(c, 0);
+    float* d_pose = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_pose), (size_t)B * 12 * sizeof(float)));
+    int rc = DAVO_OK;
+    const int save_precision = c->precision, save_impl = c->impl;
+    c->precision = 1; c->impl = 0;
+    // A layer computed from badly ranged inputs still has about the right magnitude, so each pass fixes at
+    // least the first badly ranged layer exactly and the later ones to within a few powers of two.
+    for (int pass = 0; pass < 8 && rc == DAVO_OK; ++pass) {
+        if (hipMemset(c->d_range, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = fail(c, DAVO_ERR_HIP, "hipMemset failed"); break; }
+        rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
+        if (rc) break;
+        unsigned raw[6];
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(c, DAVO_ERR_HIP, "reading the activation ranges failed");
+            break;
+        }
+        bool changed = false;
+        for (int i = 0; i < 6; ++i) {
+            float v;
+            memcpy(&v, &raw[i], sizeof v);
+            int delta = 0;
+            if (!std::isfinite(v)) delta = -32;
+            else if (v > 0.f) { int e; (void)frexpf(v, &e); delta = 10 - e; }        // stored max -> [2^9, 2^10): 64x headroom
+            int ns = c->act_shift[i] + delta;
+            ns = ns < -60 ? -60 : (ns > 60 ? 60 : ns);
+            if (ns != c->act_shift[i]) { c->act_shift[i] = ns; changed = true; }
+        }
+        if (!changed) break;
+    }
+    c->precision = save_precision; c->impl = save_impl;
+    (void)hipMemset(c->d_range, 0, 8 * sizeof(unsigned));
+    (void)hipFree(d_pose);
+    if (rc == DAVO_OK && shifts_out) for (int i = 0; i < 6; ++i) shifts_out[i] = c->act_shift[i];
+    return rc;
 }
 
 const char* davo_last_error(const davo_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -1239,7 +1344,7 @@ void davo_destroy(davo_ctx* c) {
     }
     for (auto e : c->copy_done) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    void* misc[] = {c->d_pose_tiles, c->d_w1patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
+    void* misc[] = {c->d_range, c->d_pose_tiles, c->d_w1patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
     for (auto& pe : c->prof_entries)
         for (auto& ab : pe.pending) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
@@ -1401,13 +1506,15 @@ int davo_debug_read(davo_ctx* c, const char* tensor, float* host_out, size_t n_f
         const char* names[6] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6"};
         for (int i = 0; i < 6; ++i) if (t == names[i]) ch = c->act_ch[i];
         const int cb = ch < 32 ? ch : 32;
+        int shift = 0;
+        for (int i = 0; i < 6; ++i) if (t == names[i]) shift = c->act_shift[i];
         std::vector<float> tmp(ch);
         const size_t npix = n / ch;
         for (size_t px = 0; px < npix; ++px) {
             const _Float16* raw = reinterpret_cast<const _Float16*>(host_out + px * ch);
             for (int k = 0; k < ch; ++k) {
                 const _Float16* blk = raw + (size_t)(k / cb) * cb * 2;
-                tmp[k] = (float)blk[k % cb] + (float)blk[cb + k % cb];
+                tmp[k] = ldexpf((float)blk[k % cb] + (float)blk[cb + k % cb], -shift);
             }
             memcpy(host_out + px * ch, tmp.data(), ch * sizeof(float));
         }
@@ -1480,7 +1587,7 @@ int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, c
             p.cb_log2 = L.cb_log2; p.tpc_log2 = L.tpc_log2; p.cpb = L.cpb; p.nchunks = L.nchunks_h;
             p.w_row_bytes = (long)L.nchunks_h * 128; p.y_mode = 0; p.y_ld = Cout; p.Cout = Cout;
             p.pad_t = pt; p.pad_l = pl; p.rate = rate; p.M = N * Ho * Wo; p.ntaps = k * k;
-            p.ntiles_n = L.npad_h / ts.bn; p.relu = relu; p.out_scale = 1.0f / L.wscale;
+            p.ntiles_n = L.npad_h / ts.bn; p.relu = relu; p.out_scale = 1.0f / L.wscale; p.bias_scale = L.wscale; p.range = nullptr;
             dim3 grid((p.M + ts.bm - 1) / ts.bm * p.ntiles_n, 1);
             hipError_t le = hipErrorInvalidValue;
             if (stride == 1) {

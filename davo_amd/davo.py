@@ -19,7 +19,12 @@ class DavoError(RuntimeError):
     pass
 
 
-_PY_ERR = {-1: ValueError, -2: DavoError, -3: DavoError, -4: MemoryError}
+class DavoRangeError(DavoError):
+    """f16x3: a layer's activations left the fp16-pair storage range (include/davo_hip.h: DAVO_ERR_RANGE);
+    Engine.calibrate(...) or Engine.set_precision('f32') resolves it."""
+
+
+_PY_ERR = {-1: ValueError, -2: DavoError, -3: DavoError, -4: MemoryError, -5: DavoRangeError}
 
 
 class _PinnedBlock:
@@ -128,6 +133,40 @@ class Engine:
         self._check(self._L.davo_forward(self._ctx, B, img.ctypes.data_as(vp), flow.ctypes.data_as(vp),
                                          seg.ctypes.data_as(vp), out.ctypes.data_as(vp)))
         return out
+
+    LAYERS = ("cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6")
+
+    def calibrate(self, img, flow, seg):
+        """Choose the power-of-two storage scales of the f16x3 activations from a sample batch
+        (include/davo_hip.h: davo_calibrate).  -> {layer: log2 scale}."""
+        img = np.ascontiguousarray(img, np.uint8)
+        flow = np.ascontiguousarray(flow, np.float32)
+        seg = np.ascontiguousarray(seg, np.float32)
+        B = img.shape[0]
+        if img.shape != (B, self.H, 3 * self.W, 3) or flow.shape != (B, 4, self.H, self.W, 2) or seg.shape != (B, 3, self.H, self.W, 1):
+            raise ValueError("calibration batch shapes %s %s %s do not match the engine" % (img.shape, flow.shape, seg.shape))
+        bufs = [self.alloc(a.nbytes).upload(a) for a in (img, flow, seg)]
+        shifts = (ctypes.c_int * 6)()
+        try:
+            self._check(self._L.davo_calibrate(self._ctx, B, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, shifts))
+        finally:
+            for b in bufs:
+                b.free()
+        return dict(zip(self.LAYERS, list(shifts)))
+
+    def activation_range(self, reset=False):
+        """-> ({layer: largest |activation| stored since the last reset}, {layer: log2 storage scale})."""
+        mx, sh = (ctypes.c_float * 6)(), (ctypes.c_int * 6)()
+        self._check(self._L.davo_activation_range(self._ctx, mx, sh, int(bool(reset))))
+        return dict(zip(self.LAYERS, list(mx))), dict(zip(self.LAYERS, list(sh)))
+
+    def set_activation_shifts(self, shifts=None):
+        """Install storage scales from an earlier calibrate() (dict or sequence of 6 ints; None = none)."""
+        if shifts is None:
+            self._check(self._L.davo_set_activation_shifts(self._ctx, None))
+            return
+        vals = [shifts[k] for k in self.LAYERS] if isinstance(shifts, dict) else list(shifts)
+        self._check(self._L.davo_set_activation_shifts(self._ctx, (ctypes.c_int * 6)(*vals)))
 
     def forward_device(self, B, d_img, d_flow, d_seg, d_pose, timed=False):
         ms = ctypes.c_float(0.0)
@@ -245,6 +284,13 @@ class DAVO(object):
         self._weights = weights
         if self.engine is not None:
             self.engine.load_weights(weights)
+
+    def calibrate(self, inputs):
+        """Range-calibrate the f16x3 arithmetic on a sample batch (img, flow, seg); see Engine.calibrate.  The
+        reference's float32 graph has no counterpart; a checkpoint whose activations sit far from O(1) needs it."""
+        if self.engine is None:
+            raise DavoError("setup_inference(..., mode='davo') has not been called")
+        return self.engine.calibrate(*inputs)
 
     def inference(self, sess=None, mode='pose', inputs=None):
         """davo.py:1553-1569: -> {'pose': float32 [B,2,6]}; ``sess`` is accepted and ignored."""

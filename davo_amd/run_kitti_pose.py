@@ -36,6 +36,8 @@ def main(argv=None):
     ap.add_argument("--ckpt_file", default=None)
     ap.add_argument("--version", default=FLAGSHIP_VERSION)
     ap.add_argument("--synthetic", type=int, default=0, help="frame count of a synthetic sequence")
+    ap.add_argument("--no_calibrate", action="store_true",
+                    help="skip the activation-range calibration of the f16x3 arithmetic (include/davo_hip.h: davo_calibrate)")
     ap.add_argument("--loader_threads", type=int, default=4, help="decode/read threads of the input pipeline (as data_loader.py:283-288; more threads contend on the GIL)")
     ap.add_argument("--decode_procs", type=int, default=0,
                     help="extra JPEG decode processes, for Pillow builds that hold the GIL while decoding; 0 = decode in the loader threads")
@@ -79,6 +81,9 @@ def main(argv=None):
     system.load_weights(weights)
     system.setup_inference(H, W, "davo", a.seq_length, a.batch_size)
     infer = lambda img, flow, seg: system.inference(None, "pose", inputs=(img, flow, seg))["pose"]   # noqa: E731
+    if not a.no_calibrate:
+        # every rank calibrates on the same first windows, so the trajectory does not depend on the world size
+        system.calibrate(load(0, min(a.batch_size, n_frames - 2)))
 
     t0 = time.perf_counter()
     traj, poses = S.run_sequence(infer, load, n_frames, a.batch_size, rank, world, device)

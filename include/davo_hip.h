@@ -28,7 +28,8 @@ typedef enum {
     DAVO_ERR_INVALID = -1,      /* bad argument / shape / unsupported variant */
     DAVO_ERR_HIP = -2,          /* a HIP runtime call failed                   */
     DAVO_ERR_NOT_READY = -3,    /* forward before every weight was loaded      */
-    DAVO_ERR_NOMEM = -4
+    DAVO_ERR_NOMEM = -4,
+    DAVO_ERR_RANGE = -5         /* f16x3: a layer's activations left the fp16-pair storage range */
 } davo_status;
 
 /* What the reference derives from the --version string (davo.py:1010-1102,1117-1450);
@@ -125,6 +126,21 @@ int davo_last_plan(davo_ctx* ctx, int layer, int launch, int* mtiles, int* bn);
  *      activations must stay within the fp16 range (|x| <= 65504, clamped).
  *   0 "f32": v_mfma_f32_32x32x2_f32, bit-for-bit float32 fmaf chains, no range restriction. */
 int davo_set_precision(davo_ctx* ctx, int precision);
+
+/* f16x3 range management.  Activations between layers are stored as fp16 (hi, lo) pairs; a layer's values must
+ * stay below 65504 (they are clamped there) and its largest value above ~2^-11 for the pairs to carry float32-grade
+ * precision.  Each storing kernel records the largest value it wrote; davo_forward checks the record of its own call
+ * and returns DAVO_ERR_RANGE (poses are still written) if a layer left the range.  davo_calibrate runs the path on
+ * a sample batch (device buffers, as davo_forward_device) and gives every layer an exact power-of-two storage
+ * scale that puts its largest value in [512, 1024); results inside the safe range do not depend on the scales
+ * beyond rounding noise (~1e-8).  The reference's float32 graph needs none of this (TF conv2d, nets/posenn.py:205-215);
+ * mode 0 (f32) ignores the scales.
+ *   davo_activation_range: max_abs[6] = largest |activation| written by cnv1..cnv6 since the last reset (true
+ *     magnitudes), shifts[6] = log2 of the storage scales; either may be NULL.  Synchronises.
+ *   davo_set_activation_shifts: install scales from an earlier calibration (NULL = all zero). */
+int davo_calibrate(davo_ctx* ctx, int batch, const void* d_img, const void* d_flow, const void* d_seg, int* shifts_out);
+int davo_activation_range(davo_ctx* ctx, float* max_abs, int* shifts, int reset);
+int davo_set_activation_shifts(davo_ctx* ctx, const int* shifts);
 
 /* Kernel-fusion switches of the f16x3 path (both modes give the same poses to ~1e-7):
  *   "fuse_pose" (default 1): pred 1x1 + spatial mean + 0.01 (nets/posenn.py:240-250) run in cnv7's

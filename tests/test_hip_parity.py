@@ -289,6 +289,83 @@ def test_host_entry_chunked_copy_and_pinned_buffers():
     del pin
 
 
+@pytest.mark.parametrize("shift", [-8, 6])
+def test_activation_scale_robustness(c_oracle, shift):
+    """ReLU is positively homogeneous: cnv3 (weights, bias) * 2^s and cnv4 weights * 2^-s is the same network with
+    cnv3's activations scaled by 2^s.  The split-fp16 operands must hold the 1e-4 bar when a layer's activations
+    are small (lo parts in the fp16 subnormal range, s=-8) or large (s=6), as a trained checkpoint may have them."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(2, 64, 96)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    w2 = dict(weights)
+    k = np.float32(2.0 ** shift)
+    w2["pose_exp_net/cnv3/weights"] = weights["pose_exp_net/cnv3/weights"] * k
+    w2["pose_exp_net/cnv3/biases"] = weights["pose_exp_net/cnv3/biases"] * k
+    w2["pose_exp_net/cnv4/weights"] = weights["pose_exp_net/cnv4/weights"] / k
+    for precision in PRECISIONS:
+        e = _engine(cfg, 64, 96, 2, w2, precision)
+        assert_pose_close(e.forward(img, flow, seg), want, "cnv3 activations x 2^%d, %s" % (shift, precision))
+        e.close()
+
+
+def _rescaled(weights, shift):
+    k = np.float32(2.0 ** shift)
+    w2 = dict(weights)
+    w2["pose_exp_net/cnv3/weights"] = weights["pose_exp_net/cnv3/weights"] * k
+    w2["pose_exp_net/cnv3/biases"] = weights["pose_exp_net/cnv3/biases"] * k
+    w2["pose_exp_net/cnv4/weights"] = weights["pose_exp_net/cnv4/weights"] / k
+    return w2
+
+
+@pytest.mark.parametrize("shift", [-22, 16])
+def test_range_guard_and_calibration(c_oracle, shift):
+    """A checkpoint whose cnv3 activations are ~2^-22 (fp16 pairs lose their bits) or ~2^16 (beyond the fp16
+    maximum): the host entry point refuses loudly (DAVO_ERR_RANGE), calibrate() moves the layer's storage scale,
+    and the poses then meet the bar like any other checkpoint."""
+    from davo_amd import DavoRangeError
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(2, 64, 96)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    e = _engine(cfg, 64, 96, 2, _rescaled(weights, shift), "f16x3")
+    with pytest.raises(DavoRangeError, match="cnv3 activations"):
+        e.forward(img, flow, seg)
+    shifts = e.calibrate(img, flow, seg)
+    e0 = _engine(cfg, 64, 96, 2, weights, "f16x3")
+    plain = e0.calibrate(img, flow, seg)
+    e0.close()
+    plain["cnv3"] -= shift                                                # cnv3's storage scale absorbs the 2^shift
+    assert shifts == plain, (shifts, plain)
+    assert_pose_close(e.forward(img, flow, seg), want, "calibrated, cnv3 x 2^%d" % shift)
+    mx, sh = e.activation_range()
+    assert sh == shifts and all(256 <= mx[k] * 2.0 ** sh[k] < 2048 for k in mx), (mx, sh)
+    e.set_precision("f32")                                                # the f32 mode never needed it
+    assert_pose_close(e.forward(img, flow, seg), want, "f32, cnv3 x 2^%d" % shift)
+    e.close()
+
+
+def test_calibration_is_neutral_for_a_well_ranged_checkpoint(c_oracle):
+    """Power-of-two storage scales are exact: calibrating the ordinary checkpoint moves the poses by rounding noise
+    only, activations read back unscaled, and the scales can be saved and re-installed."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(3, 64, 96)
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, 64, 96, 3, weights, "f16x3")
+    before = e.forward(img, flow, seg).copy()
+    act_before = e.debug_read("cnv4", (6, 16, 24, 128)).copy()
+    shifts = e.calibrate(img, flow, seg)
+    after = e.forward(img, flow, seg).copy()
+    assert np.abs(after - before).max() <= 1e-6 * np.abs(before).max()       # rounding noise of the re-ranged lo halves
+    assert_layer_close(e.debug_read("cnv4", (6, 16, 24, 128)), act_before, "cnv4 after calibration", rtol=1e-6)
+    assert_pose_close(after, c_oracle.forward(cfg, img, flow, seg, weights), "calibrated")
+    e.set_activation_shifts(None)
+    assert np.array_equal(e.forward(img, flow, seg), before)
+    e.set_activation_shifts(shifts)
+    assert np.array_equal(e.forward(img, flow, seg), after)
+    e.close()
+
+
 # ---- BASELINE.json configurations at full size ---------------------------------------------------
 def test_config2_batch32_full_size(c_oracle):
     """configs[1]: B=32, 128x416 — every window against the C oracle (multi-launch plan, remainder tiles)."""
