@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-end measurement set, run ON the GPU box:   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r01f'
+# Leaves under gpurun_out/: bench_<tag>32.json (full bench line incl. cpu_baseline), bench_<tag>128.json,
+# bench_<tag>64_256x832.json, and the rocprofv3 directories prof_stats / prof_fetch / prof_write / prof_sq, which
+#   python tools/prof_summary.py --stats gpurun_out/prof_stats --fetch gpurun_out/prof_fetch \
+#       --write gpurun_out/prof_write --sq gpurun_out/prof_sq --out profiles/<tag>_bench_b32_f16x3
+# condenses into profiles/.  Counters are collected in their own runs, one --pmc pass each (MI355X_MICROARCH.md, HBM).
+set -u
+TAG=${1:-rXX}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out
+mkdir -p "$O"
+python3 "$R/bench.py" > "$O/bench_${TAG}32.json" 2> "$O/bench_${TAG}32.err"; echo "bench rc=$?"
+python3 "$R/bench.py" --batch 128 --no-cpu-baseline > "$O/bench_${TAG}128.json" 2>/dev/null
+python3 "$R/bench.py" --height 256 --width 832 --batch 64 --no-cpu-baseline > "$O/bench_${TAG}64_256x832.json" 2>/dev/null
+for f in 32 128 64_256x832; do
+  python3 -c "import json; d=json.loads(open('$O/bench_${TAG}$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['pipelined']['value'])"
+done
+cd /tmp
+rm -rf "$O"/prof_*
+S="--steps 3 --warmup 1 --no-cpu-baseline --no-pipelined"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_stats" -- python3 "$R/bench.py" --no-cpu-baseline --no-pipelined > "$O/prof_stats.log" 2>&1; echo "stats rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/prof_fetch" -- python3 "$R/bench.py" $S > "$O/prof_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/prof_write" -- python3 "$R/bench.py" $S > "$O/prof_write.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+  --output-format csv -d "$O/prof_sq" -- python3 "$R/bench.py" $S > "$O/prof_sq.log" 2>&1
+echo pmc_done
