@@ -976,7 +976,6 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     c->packed_valid = !fused;
     c->last_img = d_img; c->last_flow = d_flow; c->last_seg = d_seg;
     c->packed_ld = c->impl == 0 ? 8 : 10;
-    (void)0;
     if (!fused) {
         ProfScope ps(c, "mask_pack");
         if (h3)
