@@ -343,7 +343,12 @@ hipError_t launch_h3_tile(int tile, const ConvParamsH& p, dim3 grid, hipStream_t
         if (tile == TILE_256x64) return launch_h3_c<KS, STRIDE, 4, 2, 2, 1, LAYER, SMALLC>(p, grid, s);
     if constexpr (MAXBN >= 128) {
         if (tile == TILE_256x128) return launch_h3_c<KS, STRIDE, 4, 2, 2, 2, LAYER, SMALLC>(p, grid, s);
-        if (tile == TILE_128x128) return launch_h3_c<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC>(p, grid, s);
+        if (tile == TILE_128x128) {
+            // cnv7 (stride 2, pose head in the epilogue): four waves of 64x64 measured 7 % faster than eight of
+            // 32x64 (fewer LDS fragment reads per MFMA); the stride-1 layers measured the other way round
+            if constexpr (LAYER == 7) return launch_h3_c<KS, STRIDE, 2, 2, 2, 2, LAYER, SMALLC>(p, grid, s);
+            else return launch_h3_c<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC>(p, grid, s);
+        }
     }
     if constexpr (MAXBN >= 256 && LAYER != 0) {
         if (tile == TILE_128x256) return launch_h3_c<KS, STRIDE, 2, 4, 2, 2, LAYER, SMALLC>(p, grid, s);
@@ -559,7 +564,8 @@ void init_layer(ConvLayer& L, const char* label, int KS, int stride, int rate, i
     L.tile_h = -1;                                           // -1: the planner picks per launch
     if (const char* e = getenv("DAVO_H3_TILE")) {            // measurement only: force a tile where it fits
         const int t = atoi(e);
-        if (t >= 0 && t < NUM_TILES && cout >= tile_shape(t).bn) L.tile_h = t;
+        const char* only = getenv("DAVO_H3_TILE_LABEL");     // restrict the force to one layer ("cnv4")
+        if (t >= 0 && t < NUM_TILES && cout >= tile_shape(t).bn && (!only || strcmp(only, L.label) == 0)) L.tile_h = t;
     }
     const int gran = cout > 128 ? 256 : cout > 64 ? 128 : cout > 32 ? 64 : 32;    // widest N tile a launch may use
     L.npad_h = (cout + gran - 1) / gran * gran;
