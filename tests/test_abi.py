@@ -56,3 +56,12 @@ def test_product_does_not_import_oracle():
                 # no import, path or library reference (plain prose in a comment is fine)
                 assert not re.search(r"import\s+oracle|from\s+oracle|oracle[./]|libdavo_oracle|c_oracle", txt), \
                     os.path.join(dirpath, f)
+
+
+def test_c_example_compiles_against_the_header(tmp_path):
+    """examples/c_abi_pose.c: plain C, only include/davo_hip.h, links against the built library."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(root, "include"),
+                           "-o", str(tmp_path / "c_abi_pose"), os.path.join(root, "examples", "c_abi_pose.c"),
+                           "-L", os.path.join(root, "davo_amd"), "-ldavo_hip", "-Wl,-rpath," + os.path.join(root, "davo_amd"), "-lm"])

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) vs the CPU oracle and the committed
 golden outputs.  Bar: max|pose - ref| <= 1e-4 AND <= 1e-4*max|ref|.
 The oracle is the checker only; nothing here falls back to it."""
+import os
+
 import numpy as np
 import pytest
 
@@ -363,6 +365,35 @@ def test_calibration_is_neutral_for_a_well_ranged_checkpoint(c_oracle):
     assert np.array_equal(e.forward(img, flow, seg), before)
     e.set_activation_shifts(shifts)
     assert np.array_equal(e.forward(img, flow, seg), after)
+    e.close()
+
+
+def test_c_caller(tmp_path):
+    """The C ABI stands on its own: examples/c_abi_pose.c (gcc, no Python, no HIP headers) gives the same bits as the
+    Python host class over the same entry points."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_pose")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), "-o", exe, os.path.join(root, "examples", "c_abi_pose.c"),
+                           "-L", os.path.join(root, "davo_amd"), "-ldavo_hip", "-Wl,-rpath," + os.path.join(root, "davo_amd"), "-lm"])
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B, H, W = 3, 64, 96
+    img, flow, seg = synth.make_inputs(B, H, W)
+    weights = synth.make_weights(cfg)
+    with open(tmp_path / "w.bin", "wb") as f:
+        for name, a in weights.items():
+            a = np.ascontiguousarray(a, np.float32)
+            f.write(struct.pack("<I", len(name)) + name.encode() + struct.pack("<I", a.ndim) + struct.pack("<%dq" % a.ndim, *a.shape))
+            f.write(a.tobytes())
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<3i", B, H, W) + img.tobytes() + flow.tobytes() + seg.tobytes())
+    out = subprocess.run([exe, str(tmp_path / "w.bin"), str(tmp_path / "in.bin"), str(tmp_path / "poses.bin")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = np.fromfile(tmp_path / "poses.bin", np.float32).reshape(B, 2, 6)
+    e = _engine(cfg, H, W, B, weights, "f16x3")
+    assert np.array_equal(got, e.forward(img, flow, seg))
     e.close()
 
 
