@@ -232,9 +232,11 @@ def read_checkpoint(prefix, names=None, verify_crc=False):
             if name not in entries:
                 raise KeyError("checkpoint %s has no variable `%s'" % (prefix, name))
             e = entries[name]
+            dt = _DT.get(e.get(1, [0])[0])
+            if names is None and (7 in e or dt is None):
+                continue            # reading everything: leave out what the path never needs (string/sliced entries)
             if 7 in e:
                 raise ValueError("`%s' is a sliced (partitioned) variable: not supported" % name)
-            dt = _DT.get(e.get(1, [0])[0])
             if dt is None:
                 raise ValueError("`%s': unsupported dtype enum %s" % (name, e.get(1)))
             shape = [_signed64(_parse_proto(d).get(1, [0])[0]) for d in _parse_proto(e.get(2, [b""])[0]).get(2, [])]

@@ -88,3 +88,15 @@ def test_footer_layout(tmp_path):
     T.write_checkpoint(prefix, {"x": np.zeros(1, np.float32)})
     raw = open(prefix + ".index", "rb").read()
     assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57 and len(raw) >= 48
+
+
+def test_entries_the_path_never_needs_are_skipped_not_fatal(tmp_path, monkeypatch):
+    """A training checkpoint also holds optimizer slots, global_step and (newer TF) string entries: reading
+    everything leaves out dtypes the reader does not know; asking for such an entry by name still raises."""
+    prefix = str(tmp_path / "model-7")
+    T.write_checkpoint(prefix, {"global_step": np.array(7, np.int64), "pose_exp_net/cnv1/biases": np.arange(16, dtype=np.float32)})
+    monkeypatch.setitem(T._DT, 9, None)                                   # pretend int64 is an unknown dtype
+    got = T.read_checkpoint(prefix)
+    assert list(got) == ["pose_exp_net/cnv1/biases"]
+    with pytest.raises(ValueError, match="unsupported dtype"):
+        T.read_checkpoint(prefix, names=["global_step"])
