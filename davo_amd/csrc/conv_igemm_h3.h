@@ -85,6 +85,12 @@ template <int WM, int WN, int TM, int TN> struct TileH {
     static_assert(A_LOADS >= 1 && A_LOADS <= 4 && B_LOADS >= 1 && B_LOADS <= 4, "staging shape");
 };
 
+typedef __attribute__((address_space(3))) const uint8_t lds_u8_t;
+// 32-bit LDS address of a pointer into shared memory (operand of ds_read_*)
+__device__ __forceinline__ unsigned lds_u32(const uint8_t* p) {
+    return (unsigned)(unsigned long)(lds_u8_t*)p;
+}
+
 __device__ __forceinline__ half8 lds_frag(const uint8_t* p) {
     return *reinterpret_cast<const half8*>(p);
 }
@@ -177,8 +183,7 @@ void conv_igemm_h3(ConvParamsH p) {
         __builtin_amdgcn_global_load_lds((gptr_t*)(wq + boff[j_]),                                 \
                                          (lptr_t*)(b_ + (j_ * T::ROWS_PER_PASS + 8 * wave_u) * 128), 16, 0, 0);
     // (cblk, tq) walk the chunks in order: scalar counters instead of a division per chunk
-#define H3_DMA_CHUNK(q_, buf_)                                                                     \
-    {                                                                                              \
+#define H3_DMA_SETUP(q_, buf_)                                                                     \
         const int tap = SMALLC ? (dma_tq << p.tpc_log2) + tap_in_chunk : dma_tq;                   \
         const int ky = tap / KS, kx = tap - ky * KS;                                               \
         const int dy = ky * p.rate, dx = kx * p.rate;                                              \
@@ -186,10 +191,26 @@ void conv_igemm_h3(ConvParamsH p) {
         const long delta = ((long)dy * p.Win + dx) * p.x_pix_bytes + (long)dma_cblk * (cb * 4);    \
         uint8_t* a_ = As + (buf_) * BMH * 128;                                                     \
         uint8_t* b_ = Bs + (buf_) * BNH * 128;                                                     \
+        const uint8_t* wq = wg + (long)(q_) * 128;
+#define H3_DMA_ADVANCE if (++dma_tq == p.cpb) { dma_tq = 0; ++dma_cblk; }
+    // slot s of the 8 DMA issue slots of a chunk: 0..3 = A rows, 4..7 = B rows
+#define H3_DMA_SLOT(s_)                                                                            \
+    {                                                                                              \
+        if constexpr ((s_) == 0) H3_DMA_A(0)                                                       \
+        if constexpr ((s_) == 1) H3_DMA_A(1)                                                       \
+        if constexpr ((s_) == 2) H3_DMA_A(2)                                                       \
+        if constexpr ((s_) == 3) H3_DMA_A(3)                                                       \
+        if constexpr ((s_) == 4) H3_DMA_B(0)                                                       \
+        if constexpr ((s_) == 5) H3_DMA_B(1)                                                       \
+        if constexpr ((s_) == 6) H3_DMA_B(2)                                                       \
+        if constexpr ((s_) == 7) H3_DMA_B(3)                                                       \
+    }
+#define H3_DMA_CHUNK(q_, buf_)                                                                     \
+    {                                                                                              \
+        H3_DMA_SETUP(q_, buf_)                                                                     \
         H3_DMA_A(0) H3_DMA_A(1) H3_DMA_A(2) H3_DMA_A(3)                                            \
-        const uint8_t* wq = wg + (long)(q_) * 128;                                                 \
         H3_DMA_B(0) H3_DMA_B(1) H3_DMA_B(2) H3_DMA_B(3)                                            \
-        if (++dma_tq == p.cpb) { dma_tq = 0; ++dma_cblk; }                                         \
+        H3_DMA_ADVANCE                                                                             \
     }
     int dma_cblk = 0, dma_tq = 0;
     // one 32-k chunk = two K=16 MFMA steps; per step and output tile: hi*hi, hi*lo, lo*hi
@@ -237,6 +258,83 @@ void conv_igemm_h3(ConvParamsH p) {
                 c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16h[i], bl[j], c_, 0, 0, 0);          \
                 c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16l[i], bh[j], c_, 0, 0, 0);          \
             }                                                                                      \
+    }
+    // 16x16x32 form, whole chunk, software-pipelined by hand.  The A fragments (NI row groups, hi and lo) are
+    // read once per chunk; the B fragments of column group j + 2 are requested before the MFMAs of group j are
+    // queued, so their LDS latency hides behind 6*NI matrix instructions and only the first reads of a chunk
+    // are exposed.  (Left to the compiler, the loop nest reads a whole half-step's fragments, waits for
+    // lgkmcnt(0) and only then starts the matrix pipe - twice per chunk; with the reads written as builtins it
+    // still waited for lgkmcnt(0) at every group.)  The reads are inline asm so that the waits can be counted:
+    // LDS returns in order, so "lgkmcnt(n)" = everything but the newest n reads has landed; each wait names the
+    // fragments it releases as in/out operands, which keeps the matrix instructions that use them behind it.
+    // Per accumulator the products still arrive as hi*hi, hi*lo, lo*hi per chunk: bitwise the same sums as before.
+#define H3_RD(dst_, addr_, off_) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_) : "memory")
+#define H3_WAIT_B(n_, x_) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x_) : "n"(n_))
+#define H3_WAIT_A(n_, arr_)                                                                        \
+    {                                                                                              \
+        if constexpr (NI == 4)                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(arr_[0]), "+v"(arr_[1]), "+v"(arr_[2]), "+v"(arr_[3]) : "n"(n_)); \
+        else                                                                                       \
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(arr_[0]), "+v"(arr_[1]) : "n"(n_));        \
+    }
+#define H3_MFMA_ROW(aarr_, bfrag_, J_)                                                             \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i)                                                 \
+        acc16[i][J_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aarr_[i], bfrag_, acc16[i][J_], 0, 0, 0);
+#define H3_GROUP(J_)                                                                               \
+    if constexpr ((J_) < NJ) {                                                                     \
+        if constexpr ((J_) + 2 < NJ) {                                                             \
+            H3_RD(bh[(J_) + 2 < NJ ? (J_) + 2 : 0], b_h, ((J_) + 2) * 16 * ROWB);                  \
+            H3_RD(bl[(J_) + 2 < NJ ? (J_) + 2 : 0], b_l, ((J_) + 2) * 16 * ROWB);                  \
+        }                                                                                          \
+        constexpr int after = 2 * ((J_) + 1 < NJ) + 2 * ((J_) + 2 < NJ);     /* B reads newer than group J_'s */ \
+        if constexpr ((J_) == 0) {                                                                 \
+            H3_WAIT_A(1 + NI + after, a16h)                                                        \
+            H3_WAIT_B(1 + NI + after, bh[0]);                                                      \
+            H3_MFMA_ROW(a16h, bh[0], 0)                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            H3_WAIT_B(NI + after, bl[0]);                                                          \
+            H3_MFMA_ROW(a16h, bl[0], 0)                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            H3_WAIT_A(after, a16l)                                                                 \
+            H3_MFMA_ROW(a16l, bh[0], 0)                                                            \
+        } else {                                                                                   \
+            H3_WAIT_B(after, bh[J_]);                                                              \
+            H3_WAIT_B(after, bl[J_]);                                                              \
+            H3_MFMA_ROW(a16h, bh[J_], J_)                                                          \
+            H3_MFMA_ROW(a16h, bl[J_], J_)                                                          \
+            H3_MFMA_ROW(a16l, bh[J_], J_)                                                          \
+        }                                                                                          \
+        if constexpr ((J_) < NDG) {                  /* this group's share of the next chunk's DMA */ \
+            if (do_dma) {                                                                          \
+                H3_DMA_SLOT((J_) * DPG) H3_DMA_SLOT((J_) * DPG + 1)                                \
+                if constexpr (DPG == 4) { H3_DMA_SLOT((J_) * DPG + 2) H3_DMA_SLOT((J_) * DPG + 3) } \
+            }                                                                                      \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+#define H3_CHUNK16(buf_)                                                                           \
+    {                                                                                              \
+        constexpr int NI = 2 * TM, NJ = 2 * TN;                                                    \
+        static_assert((NI == 2 || NI == 4) && NJ >= 2 && NJ <= 8, "wave tile shape");              \
+        constexpr int NDG = NJ >= 8 ? 4 : 2, DPG = 8 / NDG;     /* DMA in the first NDG groups, DPG slots each */ \
+        H3_DMA_SETUP(q + NST - 1, nslot)                                                           \
+        const unsigned a0 = lds_u32(As + (buf_) * BMH * ROWB + (wm * TM * 32 + l16) * ROWB);       \
+        const unsigned b0 = lds_u32(Bs + (buf_) * BNH * ROWB + (wn * TN * 32 + l16) * ROWB);       \
+        const unsigned a_h = a0 + foff16[0], a_l = a0 + foff16[1], b_h = b0 + foff16[0], b_l = b0 + foff16[1]; \
+        half8 bh[NJ], bl[NJ];                                                                      \
+        H3_RD(a16h[0], a_h, 0);                                                                    \
+        H3_RD(a16h[1], a_h, 16 * ROWB);                                                            \
+        if constexpr (NI == 4) { H3_RD(a16h[NI - 2], a_h, 32 * ROWB); H3_RD(a16h[NI - 1], a_h, 48 * ROWB); } \
+        H3_RD(bh[0], b_h, 0);                                                                      \
+        H3_RD(bl[0], b_l, 0);                                                                      \
+        H3_RD(a16l[0], a_l, 0);                                                                    \
+        H3_RD(a16l[1], a_l, 16 * ROWB);                                                            \
+        if constexpr (NI == 4) { H3_RD(a16l[NI - 2], a_l, 32 * ROWB); H3_RD(a16l[NI - 1], a_l, 48 * ROWB); } \
+        H3_RD(bh[1], b_h, 16 * ROWB);                                                              \
+        H3_RD(bl[1], b_l, 16 * ROWB);                                                              \
+        H3_GROUP(0) H3_GROUP(1) H3_GROUP(2) H3_GROUP(3) H3_GROUP(4) H3_GROUP(5) H3_GROUP(6) H3_GROUP(7)    \
+        if (do_dma) H3_DMA_ADVANCE                                                                 \
     }
 #define H3_STEP(buf_, s_)                                                                          \
     {                                                                                              \
@@ -312,16 +410,22 @@ void conv_igemm_h3(ConvParamsH p) {
         for (int q = 0; q < p.nchunks; ++q) {
             const int nslot = slot == 0 ? NST - 1 : slot - 1; // (q + NST - 1) % NST
             const bool more = q + NST - 1 < p.nchunks;
-            // Stagger: the two waves that share a SIMD (w and w+4 of an 8-wave workgroup) would otherwise run
-            // the same phases in lockstep — both computing DMA addresses while the matrix pipe idles, then both
-            // queueing MFMAs.  The second half of the workgroup issues its DMA after its first k-step instead
-            // of before it, which offsets the partners by one address phase at no cost in synchronisation
-            // (the DMA only has to be issued somewhere inside the iteration).
-            const bool late_dma = (p.dbg & 4) ? false : (WM * WN >= 8 && wave_u >= (WM * WN) / 2);
-            if (more && !late_dma && !(p.dbg & 1)) H3_DMA_CHUNK(q + NST - 1, nslot)
-            if (!(p.dbg & 2)) H3_STEP(slot, 0)
-            if (more && late_dma && !(p.dbg & 1)) H3_DMA_CHUNK(q + NST - 1, nslot)
-            if (!(p.dbg & 2)) H3_STEP(slot, 1)
+            if constexpr (M16) {
+                // the next chunk's DMA is issued from inside the matrix groups (H3_GROUP), two or four instructions
+                // per group over the first half of the chunk: its address arithmetic runs in the shadow of queued
+                // MFMAs instead of in front of them, and every load still has half a chunk to land
+                const bool do_dma = more && !(p.dbg & 1);
+                if (!(p.dbg & 2)) H3_CHUNK16(slot)
+                else if (do_dma) H3_DMA_CHUNK(q + NST - 1, nslot)
+            } else {
+                // Stagger (32x32x16 form): the two waves that share a SIMD would otherwise run the same phases in
+                // lockstep; the second half of the workgroup issues its DMA after its first k-step
+                const bool late_dma = (p.dbg & 4) ? false : (WM * WN >= 8 && wave_u >= (WM * WN) / 2);
+                if (more && !late_dma && !(p.dbg & 1)) H3_DMA_CHUNK(q + NST - 1, nslot)
+                if (!(p.dbg & 2)) H3_STEP32(slot, 0)
+                if (more && late_dma && !(p.dbg & 1)) H3_DMA_CHUNK(q + NST - 1, nslot)
+                if (!(p.dbg & 2)) H3_STEP32(slot, 1)
+            }
             if (q + 1 < p.nchunks) {
                 if (NST == 3 && more) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
                 else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
@@ -435,9 +539,18 @@ void conv_igemm_h3(ConvParamsH p) {
 #undef H3_DMA_A
 #undef H3_DMA_B
 #undef H3_DMA_CHUNK
+#undef H3_DMA_SLOT
+#undef H3_DMA_SETUP
+#undef H3_DMA_ADVANCE
 #undef H3_COMPUTE
 #undef H3_STEP
 #undef H3_STEP16
+#undef H3_CHUNK16
+#undef H3_GROUP
+#undef H3_MFMA_ROW
+#undef H3_WAIT_A
+#undef H3_WAIT_B
+#undef H3_RD
 #undef H3_STEP32
 
 }  // namespace davo

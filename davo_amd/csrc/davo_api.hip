@@ -763,10 +763,24 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
 // ---- f16x3 launch planning -------------------------------------------------------------------
 // Same idea as plan_layer: whole rounds of the most efficient tile, then a remainder launch with a
 // smaller tile that again fills whole rounds.  Costs are in units of one round of 256x256 tiles;
-// eff = measured throughput of the tile relative to 256x256 on the K >= 1152 layers.
+// eff = measured throughput of the tile relative to 256x256 at full occupancy (B=128: cnv5, cnv6, cnv7 forced to
+// one tile shape each, re-measured after the matrix loop was software-pipelined).  The two narrow tiles keep the
+// figures fitted on the K < 600 layers that use them (cnv3, cnv4: A/B on one box, profiles/ r01f notes).
 struct TileInfo { int id, per_cu; double eff; };
-const TileInfo kTiles[] = {{TILE_256x256, 1, 1.00}, {TILE_128x256, 1, 0.83}, {TILE_256x128, 1, 0.88},
-                           {TILE_128x128, 2, 0.90}, {TILE_256x64, 1, 0.62}, {TILE_128x32, 3, 0.40}};
+TileInfo kTiles[] = {{TILE_256x256, 1, 1.00}, {TILE_128x256, 1, 0.84}, {TILE_256x128, 1, 0.84},
+                     {TILE_128x128, 2, 0.87}, {TILE_256x64, 1, 0.62}, {TILE_128x32, 3, 0.40}};
+// measurement only: DAVO_H3_EFF="e0,e1,e2,e3,e4,e5[,p4]" overrides the efficiencies (table order) and 256x64's per_cu
+void tiles_from_env() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char* e = getenv("DAVO_H3_EFF");
+    if (!e) return;
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int n = sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6);
+    for (int i = 0; i < 6 && i < n; ++i) if (v[i] > 0) kTiles[i].eff = v[i];
+    if (n >= 7 && v[6] >= 1) kTiles[4].per_cu = (int)v[6];
+}
 struct LaunchH { int row0, rows, tile; };
 
 // whole rounds run per_cu workgroups per CU side by side; in the last, partial round a CU holds
@@ -780,6 +794,7 @@ double h3_cost(const TileInfo& t, long ntiles) {
 }
 
 std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile) {
+    tiles_from_env();
     auto ntiles = [&](const TileInfo& t, int rows) {
         const TileShape ts = tile_shape(t.id);
         return (long)((rows + ts.bm - 1) / ts.bm) * (npad / ts.bn) * groups;
@@ -844,10 +859,12 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
     std::vector<LaunchH> plan = plan_layer_h3(p.M, L.npad_h, L.groups, L.tile_h);
     if (fuse_pose) {      // one launch, one tile shape no taller than an image, so a tile touches <= 2 images
         const int P = Ho * Wo;
+        tiles_from_env();
         int best = -1; double bc = 1e30;
         for (const TileInfo& t : kTiles) {
             const TileShape ts = tile_shape(t.id);
             if (ts.bn > L.npad_h || L.npad_h % ts.bn || ts.bm > P) continue;
+            if (L.tile_h >= 0 && t.id != L.tile_h) continue;             // measurement only (DAVO_H3_TILE)
             const double cst = h3_cost(t, (long)((p.M + ts.bm - 1) / ts.bm) * (L.npad_h / ts.bn) * L.groups);
             if (cst < bc) { bc = cst; best = t.id; }
         }
