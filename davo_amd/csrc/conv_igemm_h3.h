@@ -174,7 +174,7 @@ void conv_igemm_h3(ConvParamsH p) {
 #define H3_DMA_A(j_)                                                                               \
     if constexpr (T::A_LOADS > j_) {                                                               \
         const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
-        const bool ok = tap_ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win; \
+        const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;          \
         __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? abase[j_] + delta : p.zeros),              \
                                          (lptr_t*)(a_ + (j_ * T::ROWS_PER_PASS + 8 * wave_u) * 128), 16, 0, 0); \
     }
@@ -186,12 +186,13 @@ void conv_igemm_h3(ConvParamsH p) {
 #define H3_DMA_SETUP(q_, buf_)                                                                     \
         const int tap = SMALLC ? (dma_tq << p.tpc_log2) + tap_in_chunk : dma_tq;                   \
         const int ky = tap / KS, kx = tap - ky * KS;                                               \
-        const int dy = ky * p.rate, dx = kx * p.rate;                                              \
-        const bool tap_ok = SMALLC ? tap < p.ntaps : true;                                         \
+        /* a chunk with nothing to fetch (padding tap; filler DMA of the last iteration) fails every bounds test */ \
+        const bool tap_ok = (SMALLC ? tap < p.ntaps : true) && dma_on;                             \
+        const int dy = tap_ok ? ky * p.rate : -(1 << 28), dx = kx * p.rate;                        \
         const long delta = ((long)dy * p.Win + dx) * p.x_pix_bytes + (long)dma_cblk * (cb * 4);    \
         uint8_t* a_ = As + (buf_) * BMH * 128;                                                     \
         uint8_t* b_ = Bs + (buf_) * BNH * 128;                                                     \
-        const uint8_t* wq = wg + (long)(q_) * 128;
+        const uint8_t* wq = wg + (long)((q_) < p.nchunks ? (q_) : p.nchunks - 1) * 128;
 #define H3_DMA_ADVANCE if (++dma_tq == p.cpb) { dma_tq = 0; ++dma_cblk; }
     // slot s of the 8 DMA issue slots of a chunk: 0..3 = A rows, 4..7 = B rows
 #define H3_DMA_SLOT(s_)                                                                            \
@@ -207,6 +208,7 @@ void conv_igemm_h3(ConvParamsH p) {
     }
 #define H3_DMA_CHUNK(q_, buf_)                                                                     \
     {                                                                                              \
+        constexpr bool dma_on = true;                                                              \
         H3_DMA_SETUP(q_, buf_)                                                                     \
         H3_DMA_A(0) H3_DMA_A(1) H3_DMA_A(2) H3_DMA_A(3)                                            \
         H3_DMA_B(0) H3_DMA_B(1) H3_DMA_B(2) H3_DMA_B(3)                                            \
@@ -281,6 +283,14 @@ void conv_igemm_h3(ConvParamsH p) {
 #define H3_MFMA_ROW(aarr_, bfrag_, J_)                                                             \
     _Pragma("unroll") for (int i = 0; i < NI; ++i)                                                 \
         acc16[i][J_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aarr_[i], bfrag_, acc16[i][J_], 0, 0, 0);
+    // 12 (or 3*NI) matrix instructions with the group's DMA arithmetic threaded between them: one MFMA, then up to
+    // NV_ vector/scalar instructions in its shadow, a DMA issue after every third MFMA
+#define H3_ILV(NV_)                                                                                \
+    _Pragma("unroll") for (int r_ = 0; r_ < 3 * NI; ++r_) {                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        __builtin_amdgcn_sched_group_barrier(0x006, NV_, 0);                                       \
+        if (r_ % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        \
+    }
 #define H3_GROUP(J_)                                                                               \
     if constexpr ((J_) < NJ) {                                                                     \
         if constexpr ((J_) + 2 < NJ) {                                                             \
@@ -298,18 +308,21 @@ void conv_igemm_h3(ConvParamsH p) {
             __builtin_amdgcn_sched_barrier(0);                                                     \
             H3_WAIT_A(after, a16l)                                                                 \
             H3_MFMA_ROW(a16l, bh[0], 0)                                                            \
+            if constexpr (D0 == 0) {                                                               \
+                H3_DMA_SLOT(0) H3_DMA_SLOT(1) H3_DMA_SLOT(2) H3_DMA_SLOT(3)                        \
+            }                                                                                      \
         } else {                                                                                   \
             H3_WAIT_B(after, bh[J_]);                                                              \
             H3_WAIT_B(after, bl[J_]);                                                              \
+            constexpr bool dma_here = (J_) >= D0 && (J_) < D0 + NDG;                               \
+            if constexpr (dma_here) {                /* this group's share of the next chunk's DMA */ \
+                H3_DMA_SLOT(((J_) - D0) * DPG) H3_DMA_SLOT(((J_) - D0) * DPG + 1)                  \
+                if constexpr (DPG == 4) { H3_DMA_SLOT(((J_) - D0) * DPG + 2) H3_DMA_SLOT(((J_) - D0) * DPG + 3) } \
+            }                                                                                      \
             H3_MFMA_ROW(a16h, bh[J_], J_)                                                          \
             H3_MFMA_ROW(a16h, bl[J_], J_)                                                          \
             H3_MFMA_ROW(a16l, bh[J_], J_)                                                          \
-        }                                                                                          \
-        if constexpr ((J_) < NDG) {                  /* this group's share of the next chunk's DMA */ \
-            if (do_dma) {                                                                          \
-                H3_DMA_SLOT((J_) * DPG) H3_DMA_SLOT((J_) * DPG + 1)                                \
-                if constexpr (DPG == 4) { H3_DMA_SLOT((J_) * DPG + 2) H3_DMA_SLOT((J_) * DPG + 3) } \
-            }                                                                                      \
+            if constexpr (dma_here) H3_ILV(DPG == 4 ? 4 : 2)                                       \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
@@ -317,7 +330,8 @@ void conv_igemm_h3(ConvParamsH p) {
     {                                                                                              \
         constexpr int NI = 2 * TM, NJ = 2 * TN;                                                    \
         static_assert((NI == 2 || NI == 4) && NJ >= 2 && NJ <= 8, "wave tile shape");              \
-        constexpr int NDG = NJ >= 8 ? 4 : 2, DPG = 8 / NDG;     /* DMA in the first NDG groups, DPG slots each */ \
+        /* DMA issue slots: groups D0 .. D0+NDG-1, DPG slots each, all in the first half of the chunk */ \
+        constexpr int D0 = NJ >= 4 ? 1 : 0, NDG = NJ >= 8 ? 4 : 2, DPG = 8 / NDG;                  \
         H3_DMA_SETUP(q + NST - 1, nslot)                                                           \
         const unsigned a0 = lds_u32(As + (buf_) * BMH * ROWB + (wm * TM * 32 + l16) * ROWB);       \
         const unsigned b0 = lds_u32(Bs + (buf_) * BNH * ROWB + (wn * TN * 32 + l16) * ROWB);       \
@@ -334,7 +348,7 @@ void conv_igemm_h3(ConvParamsH p) {
         H3_RD(bh[1], b_h, 16 * ROWB);                                                              \
         H3_RD(bl[1], b_l, 16 * ROWB);                                                              \
         H3_GROUP(0) H3_GROUP(1) H3_GROUP(2) H3_GROUP(3) H3_GROUP(4) H3_GROUP(5) H3_GROUP(6) H3_GROUP(7)    \
-        if (do_dma) H3_DMA_ADVANCE                                                                 \
+        H3_DMA_ADVANCE                                                                             \
     }
 #define H3_STEP(buf_, s_)                                                                          \
     {                                                                                              \
@@ -414,9 +428,11 @@ void conv_igemm_h3(ConvParamsH p) {
                 // the next chunk's DMA is issued from inside the matrix groups (H3_GROUP), two or four instructions
                 // per group over the first half of the chunk: its address arithmetic runs in the shadow of queued
                 // MFMAs instead of in front of them, and every load still has half a chunk to land
-                const bool do_dma = more && !(p.dbg & 1);
+                // (the last chunk has nothing to prefetch: its slots re-load the last weight chunk and zero rows
+                // into the idle ring slot instead of branching around the interleaved code)
+                const bool dma_on = more && !(p.dbg & 1);
                 if (!(p.dbg & 2)) H3_CHUNK16(slot)
-                else if (do_dma) H3_DMA_CHUNK(q + NST - 1, nslot)
+                else if (dma_on) H3_DMA_CHUNK(q + NST - 1, nslot)
             } else {
                 // Stagger (32x32x16 form): the two waves that share a SIMD would otherwise run the same phases in
                 // lockstep; the second half of the workgroup issues its DMA after its first k-step
@@ -433,6 +449,7 @@ void conv_igemm_h3(ConvParamsH p) {
             }
             slot = slot == NST - 1 ? 0 : slot + 1;
         }
+        if constexpr (M16) __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // the last chunk's filler DMA must land before LDS is reused
     }
 
     // ---- epilogues.  Both accumulator layouts are walked through the same three helpers:
@@ -547,6 +564,7 @@ void conv_igemm_h3(ConvParamsH p) {
 #undef H3_STEP16
 #undef H3_CHUNK16
 #undef H3_GROUP
+#undef H3_ILV
 #undef H3_MFMA_ROW
 #undef H3_WAIT_A
 #undef H3_WAIT_B
