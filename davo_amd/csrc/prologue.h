@@ -117,8 +117,10 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
                                                  Variant v, int B, int H, int W, float* __restrict__ out) {
     const int W4 = W >> 2;
     const long total = (long)B * 2 * H * W4;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total) return;
+    const long gid_raw = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = gid_raw < total;
+    if (LD != 16 && !valid) return;
+    const long gid = valid ? gid_raw : total - 1;             // LD 16: every thread reaches the barrier below
     const int x4 = (int)(gid % W4);
     long t = gid / W4;
     const int y = (int)(t % H); t /= H;
@@ -163,6 +165,11 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
     }
     constexpr int OUT_FLOATS = LD == 16 ? 8 : LD;          // LD 16 = split-fp16 layout, 8 floats' worth per pixel
     float* o = out + (((size_t)(b * 2 + s) * H + y) * W + x) * OUT_FLOATS;
+    // LD 16: a thread's 4 pixels are 8 x 16 B, 128 B apart from its neighbour's - stored directly, every store
+    // instruction would touch 64 separate lines.  The workgroup's 32 KB (contiguous: output offset = gid * 128 B)
+    // go through LDS instead and leave as 1 KiB per wave instruction.  Unit t*8 + (k ^ (t&7)): 2-way bank conflicts
+    // on the way in, none on the way out.
+    __shared__ float4 stage[LD == 16 ? 256 * 8 : 1];
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
         const float mt = v.mask_rgb ? at[px] : 1.f, ms = v.mask_rgb ? as[px] : 1.f;
@@ -186,9 +193,9 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
                 hl[k] = h;
                 hl[8 + k] = (_Float16)(r[k] - (float)h);
             }
-            float4* o16 = reinterpret_cast<float4*>(o + px * 8);
-            o16[0] = *reinterpret_cast<const float4*>(&hl[0]);
-            o16[1] = *reinterpret_cast<const float4*>(&hl[8]);
+            const int t8 = threadIdx.x * 8, sw = threadIdx.x & 7;
+            stage[t8 + ((2 * px) ^ sw)] = *reinterpret_cast<const float4*>(&hl[0]);
+            stage[t8 + ((2 * px + 1) ^ sw)] = *reinterpret_cast<const float4*>(&hl[8]);
         } else if (LD == 8) {
             *reinterpret_cast<float4*>(o + px * 8) = make_float4(r[0], r[1], r[2], r[3]);
             *reinterpret_cast<float4*>(o + px * 8 + 4) = make_float4(r[4], r[5], r[6], r[7]);
@@ -196,6 +203,16 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
             float* q = o + px * 10;
             q[0] = r[0]; q[1] = r[1]; q[2] = r[2]; q[3] = 0.f; q[4] = 0.f;
             q[5] = r[3]; q[6] = r[4]; q[7] = r[5]; q[8] = r[6]; q[9] = r[7];
+        }
+    }
+    if (LD == 16) {
+        __syncthreads();
+        float4* og = reinterpret_cast<float4*>(out) + (size_t)blockIdx.x * (256 * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = i * 256 + threadIdx.x;              // physical unit; owner thread t = j >> 3
+            const int k = (j & 7) ^ ((j >> 3) & 7);           // its logical 16-byte piece
+            if ((long)blockIdx.x * 256 + (j >> 3) < total) og[(j & ~7) + k] = stage[j];
         }
     }
 }
