@@ -452,6 +452,7 @@ void conv_igemm_h3(ConvParamsH p) {
         if constexpr (M16) __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // the last chunk's filler DMA must land before LDS is reused
     }
 
+    if (p.dbg & 32) return;                                       // measurement only: no epilogue
     // ---- epilogues.  Both accumulator layouts are walked through the same three helpers:
     //   column group jj -> column inside the wave tile; (row group ii, register r) -> row inside the wave tile
     constexpr int NCG = M16 ? 2 * TN : TN, NRG = M16 ? 2 * TM : TM, NREG = M16 ? 4 : 16;
@@ -510,6 +511,44 @@ void conv_igemm_h3(ConvParamsH p) {
     const int ocb_log2 = p.y_ld >= 32 ? 5 : (p.y_ld == 16 ? 4 : 3);
     const int ocb = 1 << ocb_log2;
     float vmax = 0.f;                                                // largest |stored value| of this lane (range monitor)
+    const int mt_store = (p.dbg & 64) ? (mtile & 255) : mtile;       // 64: measurement only, stores fold onto 256 tiles
+
+    // Split store, interior tile (every row < M, every column < Cout: all but the last tile row of a launch).
+    // The general loop below costs ~35 instructions and three branches per value (64-bit address products, bounds
+    // masks, mode tests) - a fifth to a third of a layer's time.  Here: 32-bit offsets from a uniform tile base,
+    // no bounds tests, ReLU folded into the lower clamp, the lane-pair exchange as one DPP move + one byte permute.
+    if (p.y_mode == 1 && (mtile + 1) * BMH <= p.M && (ntile + 1) * BNH <= p.Cout) {
+        uint8_t* __restrict__ tbase = p.y + (long)mt_store * BMH * p.y_ld * 4;
+        const unsigned rowb = (unsigned)p.y_ld * 4u;
+        const bool odd = lane & 1;
+        // word = even lane: hi halves of channels (n, n+1); odd lane: lo halves of (n-1, n).  perm(xn, x, sel): bytes 0-3 = x
+        const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+        const float lo_clamp = p.relu ? 0.f : -65504.f;
+        unsigned coff[NCG];
+#pragma unroll
+        for (int jj = 0; jj < NCG; ++jj) {
+            const int ng = p.y_coff + grp * p.g_y_coff + ntile * BNH + wn * TN * 32 + col_of(jj);
+            coff[jj] = (unsigned)((ng >> ocb_log2) * (ocb * 4) + (ng & (ocb - 1)) * 2 + (odd ? ocb * 2 - 2 : 0));
+        }
+#pragma unroll
+        for (int ii = 0; ii < NRG; ++ii)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                const unsigned roff = (unsigned)(wm * TM * 32 + row_of(ii, r)) * rowb;
+#pragma unroll
+                for (int jj = 0; jj < NCG; ++jj) {
+                    float v = fmaxf(val_of(ii, jj, r) * p.out_scale, lo_clamp);
+                    vmax = fmaxf(vmax, fabsf(v));
+                    v = fminf(v, 65504.f);                              // fp16 range; see DESIGN.md
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                    *reinterpret_cast<unsigned*>(tbase + (roff + coff[jj])) = __builtin_amdgcn_perm(xn, x, sel);
+                }
+            }
+    } else {
 #pragma unroll
     for (int jj = 0; jj < NCG; ++jj) {
         const int n = ntile * BNH + wn * TN * 32 + col_of(jj);
@@ -520,7 +559,7 @@ void conv_igemm_h3(ConvParamsH p) {
         for (int ii = 0; ii < NRG; ++ii)
 #pragma unroll
             for (int r = 0; r < NREG; ++r) {
-                const int m = mtile * BMH + wm * TM * 32 + row_of(ii, r);
+                const int m = mt_store * BMH + wm * TM * 32 + row_of(ii, r);
                 float v = val_of(ii, jj, r) * p.out_scale;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (n_ok && m < p.M) {
@@ -544,6 +583,7 @@ void conv_igemm_h3(ConvParamsH p) {
                     }
                 }
             }
+    }
     }
     if (p.y_mode == 1 && p.range) {      // non-negative floats order like their bit patterns; inf = overflow
 #pragma unroll
