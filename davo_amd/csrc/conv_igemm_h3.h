@@ -477,15 +477,26 @@ void conv_igemm_h3(ConvParamsH p) {
             const float* wp = p.pose_w + ((long)grp * p.Cout + (n < p.Cout ? n : 0)) * 3;
             const float w0 = n < p.Cout ? wp[0] : 0.f, w1 = n < p.Cout ? wp[1] : 0.f, w2 = n < p.Cout ? wp[2] : 0.f;
             float s0 = 0.f, s1 = 0.f;
+            // out_scale is a positive power of two: max(x*s, 0) = s*max(x, 0) exactly, so the sums run on the raw
+            // accumulators and are scaled once.  A tile inside one image and inside M (uniform test) needs no
+            // per-value row tests: two instructions per value.
+            if (split_row >= BMH && row0 + BMH <= p.M) {
 #pragma unroll
-            for (int ii = 0; ii < NRG; ++ii)
+                for (int ii = 0; ii < NRG; ++ii)
 #pragma unroll
-                for (int r = 0; r < NREG; ++r) {
-                    const int row = wm * TM * 32 + row_of(ii, r);
-                    float v = fmaxf(val_of(ii, jj, r) * p.out_scale, 0.f);
-                    if (row0 + row >= p.M) v = 0.f;
-                    if (row < split_row) s0 += v; else s1 += v;
-                }
+                    for (int r = 0; r < NREG; ++r) s0 += fmaxf(val_of(ii, jj, r), 0.f);
+            } else {
+#pragma unroll
+                for (int ii = 0; ii < NRG; ++ii)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) {
+                        const int row = wm * TM * 32 + row_of(ii, r);
+                        float v = fmaxf(val_of(ii, jj, r), 0.f);
+                        if (row0 + row >= p.M) v = 0.f;
+                        if (row < split_row) s0 += v; else s1 += v;
+                    }
+            }
+            s0 *= p.out_scale; s1 *= p.out_scale;
             q[0] += s0 * w0; q[1] += s0 * w1; q[2] += s0 * w2;
             q[3] += s1 * w0; q[4] += s1 * w1; q[5] += s1 * w2;
         }
