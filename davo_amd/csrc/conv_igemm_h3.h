@@ -69,7 +69,7 @@ struct ConvParamsH {
 
 constexpr int LDB = 144;        // LDS row: 128 data bytes + 16 pad (conflict-free b128 fragment reads)
 
-template <int WM, int WN, int TM, int TN> struct TileH {
+template <int WM, int WN, int TM, int TN, int NSTG = 2> struct TileH {
     static constexpr int THREADS = WM * WN * 64;
     static constexpr int BMH = WM * TM * 32;
     static constexpr int BNH = WN * TN * 32;
@@ -80,7 +80,9 @@ template <int WM, int WN, int TM, int TN> struct TileH {
 #ifndef DAVO_H3_STAGES
 #define DAVO_H3_STAGES 2
 #endif
-    static constexpr int DMA_STAGES = DAVO_H3_STAGES;        // LDS ring slots (2 or 3)
+    // LDS ring slots: 2; the 128x128 tile of a remainder launch (one workgroup per CU, nothing else to hide the DMA
+    // latency behind) takes 3
+    static constexpr int DMA_STAGES = DAVO_H3_STAGES == 2 ? NSTG : DAVO_H3_STAGES;
     static constexpr int LDS_BYTES_DMA = DMA_STAGES * (BMH + BNH) * 128;   // LDS-DMA ring: linear rows, XOR-swizzled units
     static_assert(A_LOADS >= 1 && A_LOADS <= 4 && B_LOADS >= 1 && B_LOADS <= 4, "staging shape");
 };
@@ -109,10 +111,10 @@ typedef __attribute__((address_space(3))) void lptr_t;
 // M16: use v_mfma_f32_16x16x32_f16 (K = 32 = the whole chunk per instruction) instead of 32x32x16.  Same LDS
 // bytes and matrix cycles per chunk; under matrix-dense load the chip holds a higher clock on the 16x16 shape
 // (MI355X_MICROARCH.md, DVFS give-back item 7), so the faster one is chosen by measurement.
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC, bool M16 = false>
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC, bool M16 = false, int NSTG = 2>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 2)
 void conv_igemm_h3(ConvParamsH p) {
-    using T = TileH<WM, WN, TM, TN>;
+    using T = TileH<WM, WN, TM, TN, NSTG>;
     constexpr int BMH = T::BMH, BNH = T::BNH;
     constexpr int ROWB = DMA ? 128 : LDB;              // LDS bytes per row
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_h[];

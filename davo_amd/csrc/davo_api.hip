@@ -309,11 +309,11 @@ bool h3_use_m16() {
     return v != 0;
 }
 
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool SMALLC, bool M16>
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool SMALLC, bool M16, int NSTG = 2>
 hipError_t launch_h3_m(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
-    using T = TileH<WM, WN, TM, TN>;
-    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, true, SMALLC, M16>;
+    using T = TileH<WM, WN, TM, TN, NSTG>;
+    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, true, SMALLC, M16, NSTG>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES_DMA);
@@ -347,7 +347,14 @@ hipError_t launch_h3_tile(int tile, const ConvParamsH& p, dim3 grid, hipStream_t
             // cnv7 (stride 2, pose head in the epilogue): four waves of 64x64 measured 7 % faster than eight of
             // 32x64 (fewer LDS fragment reads per MFMA); the stride-1 layers measured the other way round
             if constexpr (LAYER == 7) return launch_h3_c<KS, STRIDE, 2, 2, 2, 2, LAYER, SMALLC>(p, grid, s);
-            else return launch_h3_c<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC>(p, grid, s);
+            else {
+                // a launch of at most one workgroup per CU (remainder rows) has no second workgroup to hide the
+                // DMA latency behind: three ring slots instead of two (cnv6.rem 0.073 -> 0.061 ms, cnv5.rem 0.041 -> 0.036)
+                if constexpr (LAYER >= 3 && !SMALLC)
+                    if ((long)grid.x * grid.y <= 256 && h3_use_m16())
+                        return launch_h3_m<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC, true, 3>(p, grid, s);
+                return launch_h3_c<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC>(p, grid, s);
+            }
         }
     }
     if constexpr (MAXBN >= 256 && LAYER != 0) {
