@@ -537,30 +537,38 @@ void conv_igemm_h3(ConvParamsH p) {
         // word = even lane: hi halves of channels (n, n+1); odd lane: lo halves of (n-1, n).  perm(xn, x, sel): bytes 0-3 = x
         const unsigned sel = odd ? 0x03020706u : 0x05040100u;
         const float lo_clamp = p.relu ? 0.f : -65504.f;
+        // column byte offsets: the wave's first channel is a multiple of 32 (checked: blocks of 32 channels, 64 B of hi
+        // halves then 64 B of lo halves), so column group jj sits a compile-time distance from group 0 and the
+        // distance folds into the store's immediate offset
+        const int ng0 = p.y_coff + grp * p.g_y_coff + ntile * BNH + wn * TN * 32 + col_of(0);
+        const bool regular = ocb == 32 && ((ng0 - col_of(0)) & 31) == 0;
+        const unsigned coff0 = (unsigned)((ng0 >> ocb_log2) * (ocb * 4) + (ng0 & (ocb - 1)) * 2 + (odd ? ocb * 2 - 2 : 0));
         unsigned coff[NCG];
 #pragma unroll
         for (int jj = 0; jj < NCG; ++jj) {
-            const int ng = p.y_coff + grp * p.g_y_coff + ntile * BNH + wn * TN * 32 + col_of(jj);
+            const int ng = ng0 - col_of(0) + col_of(jj);
             coff[jj] = (unsigned)((ng >> ocb_log2) * (ocb * 4) + (ng & (ocb - 1)) * 2 + (odd ? ocb * 2 - 2 : 0));
         }
-#pragma unroll
-        for (int ii = 0; ii < NRG; ++ii)
-#pragma unroll
-            for (int r = 0; r < NREG; ++r) {
-                const unsigned roff = (unsigned)(wm * TM * 32 + row_of(ii, r)) * rowb;
-#pragma unroll
-                for (int jj = 0; jj < NCG; ++jj) {
-                    float v = fmaxf(val_of(ii, jj, r) * p.out_scale, lo_clamp);
-                    vmax = fmaxf(vmax, fabsf(v));
-                    v = fminf(v, 65504.f);                              // fp16 range; see DESIGN.md
-                    const _Float16 hi = (_Float16)v;
-                    const _Float16 lo = (_Float16)(v - (float)hi);
-                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
-                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                    *reinterpret_cast<unsigned*>(tbase + (roff + coff[jj])) = __builtin_amdgcn_perm(xn, x, sel);
-                }
+        constexpr int CW = M16 ? 16 : 32;                      // channels per column group
+#define H3_STORE_ROWS(COFF_)                                                                        \
+        _Pragma("unroll") for (int ii = 0; ii < NRG; ++ii)                                          \
+            _Pragma("unroll") for (int r = 0; r < NREG; ++r) {                                      \
+                uint8_t* __restrict__ rowp = tbase + ((unsigned)(wm * TM * 32 + row_of(ii, r)) * rowb + coff0); \
+                _Pragma("unroll") for (int jj = 0; jj < NCG; ++jj) {                                \
+                    float v = fmaxf(val_of(ii, jj, r) * p.out_scale, lo_clamp);                     \
+                    vmax = fmaxf(vmax, fabsf(v));                                                   \
+                    v = fminf(v, 65504.f);                              /* fp16 range; see DESIGN.md */ \
+                    const _Float16 hi = (_Float16)v;                                                \
+                    const _Float16 lo = (_Float16)(v - (float)hi);                                  \
+                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |           \
+                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);    \
+                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   /* quad_perm [1,0,3,2] */ \
+                    *reinterpret_cast<unsigned*>(rowp + (COFF_)) = __builtin_amdgcn_perm(xn, x, sel); \
+                }                                                                                   \
             }
+        if (regular) { H3_STORE_ROWS((jj * CW >> 5) * 128 + ((jj * CW) & 31) * 2) }
+        else { H3_STORE_ROWS(coff[jj] - coff0) }
+#undef H3_STORE_ROWS
     } else {
 #pragma unroll
     for (int jj = 0; jj < NCG; ++jj) {
