@@ -64,7 +64,8 @@ struct ConvParamsH {
     const float* pose_w;    // [groups][256][3] pred kernels
     float* pose_partial;    // [groups][pose_mt][ntiles_n][2 image slots][3]
     int pose_P, pose_mt;    // output pixels per image (>= tile height), M tiles in the launch
-    int dbg;                // measurement only (DAVO_DBG): bit0 skip the loop's DMA, bit1 skip its MFMA phase
+    int dbg;                // measurement only (DAVO_DBG; results are wrong with any bit set): 1 DMA reads the zero line,
+                            // 2 no matrix phase, 4 no wave-half stagger (32x32x16 form), 32 no epilogue, 64 stores fold onto 256 tiles
 };
 
 constexpr int LDB = 144;        // LDS row: 128 data bytes + 16 pad (conflict-free b128 fragment reads)
