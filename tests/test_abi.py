@@ -65,3 +65,13 @@ def test_c_example_compiles_against_the_header(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(root, "include"),
                            "-o", str(tmp_path / "c_abi_pose"), os.path.join(root, "examples", "c_abi_pose.c"),
                            "-L", os.path.join(root, "davo_amd"), "-ldavo_hip", "-Wl,-rpath," + os.path.join(root, "davo_amd"), "-lm"])
+
+
+def test_counted_lds_waits_are_safe_in_the_compiled_code():
+    """tools/check_isa.py: no scalar-memory or other LDS instruction between the hand-counted fragment reads and
+    the matrix instructions they feed, in any 16x16x32 kernel (compiles the device code to assembly: ~1-2 min)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
