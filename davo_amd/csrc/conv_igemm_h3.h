@@ -26,6 +26,10 @@
 // [32 hi | 32 lo], read as four ds_read_b128 fragments per 32-row MFMA tile.  The k order is
 // channel-block major, tap minor, so a workgroup revisits the same 32-channel slice of its
 // pixels for all taps before moving on (L2 / L1 locality of the dilated gather).
+//
+// Range: a layer's stored activations carry an exact power-of-two scale 2^shift (davo_calibrate; 0 by default)
+// so that their fp16 pairs stay inside [2^-11, 65504); out_scale / bias_scale fold it in, the storing
+// epilogues record the largest value written (range monitor, include/davo_hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
