@@ -421,10 +421,13 @@ void conv_igemm_h3(ConvParamsH p) {
         constexpr int WAIT_KEEP = (KEEP & 15) | (7 << 4) | (15 << 8) | ((KEEP >> 4) << 14);   // vmcnt(KEEP) only
         constexpr int WAIT_ALL = (7 << 4) | (15 << 8);                                        // vmcnt(0) only
         H3_DMA_CHUNK(0, 0)
-        if constexpr (NST == 3) {
-            if (p.nchunks > 1) H3_DMA_CHUNK(1, 1)
+        if constexpr (NST >= 3) {
+            if (p.nchunks >= NST - 1) {
+                H3_DMA_CHUNK(1, 1)
+                if constexpr (NST == 4) H3_DMA_CHUNK(2, 2)
+            }
         }
-        if (NST == 3 && p.nchunks > 1) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
+        if (NST >= 3 && p.nchunks >= NST - 1) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
         else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
         __builtin_amdgcn_s_barrier();
         int slot = 0;                                         // slot of chunk q
@@ -450,7 +453,8 @@ void conv_igemm_h3(ConvParamsH p) {
                 if (!(p.dbg & 2)) H3_STEP32(slot, 1)
             }
             if (q + 1 < p.nchunks) {
-                if (NST == 3 && more) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
+                // M16: the filler DMA keeps the count of younger instructions constant, so the counted wait always holds
+                if (NST >= 3 && (more || M16) && p.nchunks >= NST - 1) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
                 else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
                 __builtin_amdgcn_s_barrier();
             }

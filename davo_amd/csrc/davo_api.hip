@@ -300,6 +300,9 @@ TileShape tile_shape(int t) {
     }
 }
 
+#ifndef DAVO_REM_STAGES
+#define DAVO_REM_STAGES 3
+#endif
 // All f16x3 launches are LDS-DMA staged.  SMALLC (Cin < 32) is a property of the layer.
 // v_mfma 16x16x32 instead of 32x32x16 for the large tiles (higher held clock under matrix-dense load);
 // DAVO_H3_M16=0 selects the 32x32x16 form (A/B measurements)
@@ -352,7 +355,7 @@ hipError_t launch_h3_tile(int tile, const ConvParamsH& p, dim3 grid, hipStream_t
                 // DMA latency behind: three ring slots instead of two (cnv6.rem 0.073 -> 0.061 ms, cnv5.rem 0.041 -> 0.036)
                 if constexpr (LAYER >= 3 && !SMALLC)
                     if ((long)grid.x * grid.y <= 256 && h3_use_m16())
-                        return launch_h3_m<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC, true, 3>(p, grid, s);
+                        return launch_h3_m<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC, true, DAVO_REM_STAGES>(p, grid, s);
                 return launch_h3_c<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC>(p, grid, s);
             }
         }
