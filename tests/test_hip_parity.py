@@ -397,6 +397,17 @@ def test_c_caller(tmp_path):
     e.close()
 
 
+def test_random_shape_sweep():
+    """tools/stress_shapes.py, 12 seeded random (H, W, B, cnv6 width, variant) cases: f16x3 vs the bit-exact f32 path,
+    a second batch size on the same windows, every sixth case against the C oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_shapes.py"), "12", "20261003"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 # ---- BASELINE.json configurations at full size ---------------------------------------------------
 def test_config2_batch32_full_size(c_oracle):
     """configs[1]: B=32, 128x416 — every window against the C oracle (multi-launch plan, remainder tiles)."""
