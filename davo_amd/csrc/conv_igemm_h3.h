@@ -36,6 +36,10 @@
 
 #include "conv_igemm.h"
 
+#ifndef DAVO_H3_NDG8
+#define DAVO_H3_NDG8 2          // 8-group chunks: matrix groups that carry the next chunk's DMA (2: four loads each, groups 1-2; 4 measured 0.5 % slower)
+#endif
+
 namespace davo {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -338,7 +342,7 @@ void conv_igemm_h3(ConvParamsH p) {
         constexpr int NI = 2 * TM, NJ = 2 * TN;                                                    \
         static_assert((NI == 2 || NI == 4) && NJ >= 2 && NJ <= 8, "wave tile shape");              \
         /* DMA issue slots: groups D0 .. D0+NDG-1, DPG slots each, all in the first half of the chunk */ \
-        constexpr int D0 = NJ >= 4 ? 1 : 0, NDG = NJ >= 8 ? 4 : 2, DPG = 8 / NDG;                  \
+        constexpr int D0 = NJ >= 4 ? 1 : 0, NDG = NJ >= 8 ? DAVO_H3_NDG8 : 2, DPG = 8 / NDG;                  \
         H3_DMA_SETUP(q + NST - 1, nslot)                                                           \
         const unsigned a0 = lds_u32(As + (buf_) * BMH * ROWB + (wm * TM * 32 + l16) * ROWB);       \
         const unsigned b0 = lds_u32(Bs + (buf_) * BNH * ROWB + (wn * TN * 32 + l16) * ROWB);       \
