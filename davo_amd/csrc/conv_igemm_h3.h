@@ -296,11 +296,11 @@ void conv_igemm_h3(ConvParamsH p) {
         acc16[i][J_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aarr_[i], bfrag_, acc16[i][J_], 0, 0, 0);
     // 12 (or 3*NI) matrix instructions with the group's DMA arithmetic threaded between them: one MFMA, then up to
     // NV_ vector/scalar instructions in its shadow, a DMA issue after every third MFMA
-#define H3_ILV(NV_)                                                                                \
+#define H3_ILV(NV_, VE_)                                                                           \
     _Pragma("unroll") for (int r_ = 0; r_ < 3 * NI; ++r_) {                                        \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
         __builtin_amdgcn_sched_group_barrier(0x006, NV_, 0);                                       \
-        if (r_ % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        \
+        if (r_ % (VE_) == (VE_) - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            \
     }
 #define H3_GROUP(J_)                                                                               \
     if constexpr ((J_) < NJ) {                                                                     \
@@ -328,12 +328,15 @@ void conv_igemm_h3(ConvParamsH p) {
             constexpr bool dma_here = (J_) >= D0 && (J_) < D0 + NDG;                               \
             if constexpr (dma_here) {                /* this group's share of the next chunk's DMA */ \
                 H3_DMA_SLOT(((J_) - D0) * DPG) H3_DMA_SLOT(((J_) - D0) * DPG + 1)                  \
-                if constexpr (DPG == 4) { H3_DMA_SLOT(((J_) - D0) * DPG + 2) H3_DMA_SLOT(((J_) - D0) * DPG + 3) } \
+                if constexpr (DPG >= 4) { H3_DMA_SLOT(((J_) - D0) * DPG + 2) H3_DMA_SLOT(((J_) - D0) * DPG + 3) } \
+                if constexpr (DPG == 8) {                                                          \
+                    H3_DMA_SLOT(4) H3_DMA_SLOT(5) H3_DMA_SLOT(6) H3_DMA_SLOT(7)                    \
+                }                                                                                  \
             }                                                                                      \
             H3_MFMA_ROW(a16h, bh[J_], J_)                                                          \
             H3_MFMA_ROW(a16h, bl[J_], J_)                                                          \
             H3_MFMA_ROW(a16l, bh[J_], J_)                                                          \
-            if constexpr (dma_here) H3_ILV(DPG == 4 ? 4 : 2)                                       \
+            if constexpr (dma_here) H3_ILV(DPG == 2 ? 2 : (DPG == 4 ? 4 : 6), DPG == 8 ? 1 : 3)    \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
