@@ -98,7 +98,7 @@ int davo_set_stream(davo_ctx* ctx, void* hip_stream);
 /* Number of batches davo_forward_device keeps in flight (1..4, default 1).  With n > 1 the context
  * owns n streams and n activation workspaces and successive calls rotate through them, so the small
  * kernels of one batch overlap the large convolutions of another (the counterpart of the
- * reference's tf.data prefetch, data_loader.py:321-324; +11 % throughput at n = 2, B = 32).  The
+ * reference's tf.data prefetch, data_loader.py:321-324; +3...7 % throughput at n = 2, B = 32).  The
  * caller must give concurrent calls distinct input/output buffers and call davo_synchronize()
  * before reading results.  davo_forward (host buffers) stays synchronous. */
 int davo_set_inflight(davo_ctx* ctx, int n);
@@ -123,7 +123,7 @@ int davo_last_plan(davo_ctx* ctx, int layer, int launch, int* mtiles, int* bn);
  *   1 (default) "f16x3": every float32 operand is split into two fp16 halves (22 significant
  *      bits) and each product is three fp16 MFMA products accumulated in float32 — float32-grade
  *      results (measured ~1e-7 relative on the 6-DoF outputs) at 5.3x less matrix-pipe time;
- *      activations must stay within the fp16 range (|x| <= 65504, clamped).
+ *      a layer's activations must stay within the fp16-pair range (see davo_calibrate below).
  *   0 "f32": v_mfma_f32_32x32x2_f32, bit-for-bit float32 fmaf chains, no range restriction. */
 int davo_set_precision(davo_ctx* ctx, int precision);
 
