@@ -98,8 +98,10 @@ __global__ __launch_bounds__(64) void se_excite(const float* __restrict__ partia
 }
 
 __device__ __forceinline__ float att_lookup(const float* tab19, float seg) {
-    const int id = (int)seg;                                   // tf.cast(float -> int32) truncates
-    return (id >= 0 && id < NCLS) ? tab19[id] : 0.f;           // one_hot: out of range -> zero row
+    // tf.cast(float -> int32) truncates toward zero; one_hot of an out-of-range id is a zero row.  NaN / inf /
+    // beyond-int32 labels are platform-defined in the cast (x86: INT_MIN, GPUs: 0 or saturation) and pinned to
+    // "no class" here: only finite values in (-1, 19) select a row (the comparison is false for NaN).
+    return (seg > -1.0f && seg < (float)NCLS) ? tab19[(int)seg] : 0.f;
 }
 
 __device__ __forceinline__ float u8_to_unit(uint32_t byte) {

@@ -148,8 +148,10 @@ static void attention_tables(const oracle_variant* v, int B, int H, int W, const
 }
 
 static inline float att_at(const float* tab19, float seg) {
-    int id = (int)seg;                               /* tf.cast(float->int32) truncates */
-    return (id >= 0 && id < NCLS) ? tab19[id] : 0.f; /* tf.one_hot: out of range -> zero row */
+    /* tf.cast(float->int32) truncates toward zero; NaN / inf / beyond-int32 inputs are platform-defined there and
+     * pinned here (and in the product) to "no class": only finite values in (-1, 19) select a row */
+    if (!(seg > -1.0f && seg < (float)NCLS)) return 0.f;   /* tf.one_hot: out of range -> zero row */
+    return tab19[(int)seg];
 }
 
 /* packed: [B,2,H,W,2*cin] (davo.py:961-1004,1404-1442; posenn.py:198) */

@@ -117,8 +117,13 @@ def attention_tables(cfg, flow, weights, dtype):
 
 def attention_map(table, seg):
     """sum_c one_hot(int32(seg),19)[...,c] * table[c]  (davo.py:1115,1178)."""
-    ids = np.trunc(seg[..., 0]).astype(np.int64)                          # [B,H,W]
-    ok = (ids >= 0) & (ids < NUM_SEG_CLASSES)
+    s = seg[..., 0]
+    # tf.cast(float -> int32) truncates toward zero; what it gives for NaN / inf / beyond int32 is the platform's
+    # (INT_MIN on x86, 0 or saturation on GPUs).  Pinned here and in the product: anything that is not a finite
+    # value in (-1, 19) selects no class (zero row of the one_hot), like every other out-of-range id.
+    inside = np.isfinite(s) & (s > -1.0) & (s < float(NUM_SEG_CLASSES))
+    ids = np.trunc(np.where(inside, s, -1.0)).astype(np.int64)            # [B,H,W]
+    ok = inside & (ids >= 0) & (ids < NUM_SEG_CLASSES)
     safe = np.where(ok, ids, 0)
     att = np.take_along_axis(table[:, None, None, :], safe[..., None], axis=-1)[..., 0]
     return np.where(ok, att, 0).astype(table.dtype)[..., None]           # [B,H,W,1]

@@ -504,11 +504,14 @@ def test_seg_label_edge_values(precision):
     (davo.py:1115): fractional, negative and ignore labels must mask exactly like the oracle says."""
     cfg = parse_version(FLAGSHIP_VERSION)
     img, flow, seg = synth.make_inputs(2, 64, 96)
-    vals = np.array([0.0, 0.9, 18.0, 18.99, 19.0, 255.0, -0.5, -3.0, 7.5, 100.0], np.float32)
+    # ... and labels the cast leaves to the platform (NaN, inf, beyond int32) select no class, here as in the oracle
+    vals = np.array([0.0, 0.9, 18.0, 18.99, 19.0, 255.0, -0.5, -3.0, 7.5, 100.0,
+                     np.nan, np.inf, -np.inf, 3e9, -3e9, -1.0, -0.999], np.float32)
     rng = np.random.RandomState(3)
     seg = vals[rng.randint(0, len(vals), size=seg.shape)].astype(np.float32)
     w = synth.make_weights(cfg)
-    want = O.forward(cfg, img, flow, seg, w)
+    with np.errstate(invalid="ignore"):
+        want = O.forward(cfg, img, flow, seg, w)
     e = _engine(cfg, 64, 96, 2, w, precision)
     assert_pose_close(e.forward(img, flow, seg), want, "edge labels %s" % precision)
     e.close()

@@ -58,6 +58,11 @@ def test_attention_lut_semantics():
     seg = np.array([0.0, 0.9, 18.0, 18.99, 19.0, 255.0, -0.5, -3.0], np.float32).reshape(1, 1, 8, 1)
     att = O.attention_map(tab, seg)[0, 0, :, 0]
     assert np.allclose(att, [0.01, 0.01, 0.19, 0.19, 0.0, 0.0, 0.01, 0.0])
+    # labels the float -> int32 cast leaves to the platform: pinned to "no class"
+    odd = np.array([np.nan, np.inf, -np.inf, 3e9, -3e9, -1.0, -0.999, 18.999], np.float32).reshape(1, 1, 8, 1)
+    with np.errstate(invalid="ignore"):
+        att = O.attention_map(tab, odd)[0, 0, :, 0]
+    assert np.allclose(att, [0, 0, 0, 0, 0, 0, 0.01, 0.19])
 
 
 def test_pack_layout_flagship(c_oracle):
