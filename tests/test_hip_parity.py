@@ -408,6 +408,20 @@ def test_random_shape_sweep():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("H,W,B", [(16, 16, 1), (16, 20, 3), (20, 16, 2), (16, 416, 1), (128, 16, 2)])
+def test_minimum_sizes(c_oracle, H, W, B):
+    """The smallest frames davo_create accepts (cnv7 output 2x2 or a single row / column of tiles): every GEMM is
+    smaller than one tile."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(B, H, W)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    for precision in PRECISIONS:
+        e = _engine(cfg, H, W, B, weights, precision)
+        assert_pose_close(e.forward(img, flow, seg), want, "%dx%d B=%d %s" % (H, W, B, precision))
+        e.close()
+
+
 # ---- BASELINE.json configurations at full size ---------------------------------------------------
 def test_config2_batch32_full_size(c_oracle):
     """configs[1]: B=32, 128x416 — every window against the C oracle (multi-launch plan, remainder tiles)."""
