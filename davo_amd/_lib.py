@@ -7,10 +7,21 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DAVO_LIB_SUFFIX selects an experimental build (tools/build_variant.py); unset = the product library
-LIB_PATH = os.path.join(_HERE, "libdavo_hip%s.so" % os.environ.get("DAVO_LIB_SUFFIX", ""))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+# translation units of the library (csrc/ctx.h lists what each one holds); built in parallel, linked into one .so
+UNITS = ("api", "forward", "plan", "weights", "launch_f32", "launch_h3", "launch_h3_generic", "launch_misc", "comm")
+
+
+def lib_path(suffix=None):
+    """DAVO_LIB_SUFFIX (or `suffix`) selects an experimental build made by tools/build_variant.py, e.g. the
+    `_tuning` library with the measurement knobs compiled in; unset = the product library."""
+    if suffix is None:
+        suffix = os.environ.get("DAVO_LIB_SUFFIX", "")
+    return os.path.join(_HERE, "libdavo_hip%s.so" % suffix)
+
+
+LIB_PATH = lib_path()
 
 EXPORTS = (
     "davo_create", "davo_load_weight", "davo_weights_missing", "davo_forward", "davo_forward_device",
@@ -18,7 +29,10 @@ EXPORTS = (
     "davo_memcpy_d2h", "davo_synchronize", "davo_set_stream", "davo_set_inflight", "davo_profile_enable",
     "davo_profile_reset", "davo_profile_entry", "davo_last_plan", "davo_set_option", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
     "davo_host_alloc", "davo_host_free", "davo_calibrate", "davo_activation_range", "davo_set_activation_shifts",
+    "davo_comm_unique_id", "davo_comm_init", "davo_comm_size", "davo_allgather_poses", "davo_allgather_poses_device",
+    "davo_comm_allreduce", "davo_comm_barrier", "davo_comm_destroy", "davo_plan_layer",
 )
+COMM_ID_BYTES = 128
 
 
 class DavoVariant(ctypes.Structure):
@@ -27,23 +41,42 @@ class DavoVariant(ctypes.Structure):
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in ("davo_api.hip", "conv_igemm.h", "conv_igemm_h3.h", "conv_patch_h3.h", "prologue.h")] + \
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + \
            [os.path.join(INCLUDE, "davo_hip.h")]
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> davo_amd/libdavo_hip.so (in-tree, so it travels to the GPU box)."""
-    if not force and os.path.exists(LIB_PATH) and \
-            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in sources()):
-        return LIB_PATH
+def build(force=False, verbose=False, suffix=None, extra_flags=()):
+    """hipcc --offload-arch=gfx950 -> davo_amd/libdavo_hip.so (in-tree, so it travels to the GPU box).
+    One object per translation unit, compiled in parallel (the f16x3 instantiations dominate), then linked."""
+    out = lib_path(suffix)
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in sources()):
+        return out
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-o", LIB_PATH, os.path.join(CSRC, "davo_api.hip"),
-           "-Wl,-rpath,/opt/rocm/lib"] + os.environ.get("DAVO_EXTRA_HIPCC_FLAGS", "").split()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+        list(extra_flags) + os.environ.get("DAVO_EXTRA_HIPCC_FLAGS", "").split()
+    objdir = os.path.join(CSRC, "build%s" % (suffix if suffix is not None else os.environ.get("DAVO_LIB_SUFFIX", "")))
+    os.makedirs(objdir, exist_ok=True)
+    headers = [s for s in sources() if s.endswith(".h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+
+    def compile_unit(u):
+        src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(objdir, u + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header):
+            return obj
+        cmd = [hipcc] + flags + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_unit, UNITS))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
 
 
 _lib = None
@@ -88,6 +121,16 @@ def lib():
     L.davo_set_impl.argtypes = [vp, i]
     L.davo_debug_read.argtypes = [vp, ctypes.c_char_p, f32p, ctypes.c_size_t]
     L.davo_conv2d_same.argtypes = [i, f32p, i, i, i, i, f32p, i, i, f32p, i, i, i, i, f32p, ctypes.c_char_p, i]
+    ip = ctypes.POINTER(i)
+    L.davo_plan_layer.argtypes = [i, i, i, ip, ip, ip]
+    L.davo_comm_unique_id.argtypes = [vp, ctypes.c_char_p, i]
+    L.davo_comm_init.argtypes = [vp, i, i, vp]
+    L.davo_comm_size.argtypes = [vp, ip, ip]
+    L.davo_allgather_poses.argtypes = [vp, f32p, i, i, f32p, f32p]
+    L.davo_allgather_poses_device.argtypes = [vp, vp, i, vp, f32p]
+    L.davo_comm_allreduce.argtypes = [vp, ctypes.POINTER(ctypes.c_double), i]
+    L.davo_comm_barrier.argtypes = [vp]
+    L.davo_comm_destroy.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("davo_last_error", "davo_destroy"):

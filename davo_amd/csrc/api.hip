@@ -1,0 +1,584 @@
+// api.hip — the extern "C" entry points of libdavo_hip.so (include/davo_hip.h): context life
+// cycle, weight loading, the host- and device-buffer forward calls, f16x3 range management,
+// measurement and test hooks.  The forward plan itself is forward.hip; kernels are reached
+// through launch.h; the RCCL communicator is comm.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "ctx.h"
+#include "launch.h"
+#include "plan.h"
+
+using namespace davo;
+
+namespace {
+
+void free_slot(Slot& s) {
+    for (auto p : s.d_act) if (p) (void)hipFree(p);
+    void* misc[] = {s.d_partial, s.d_tab, s.d_packed, s.d_pose_partial};
+    for (auto p : misc) if (p) (void)hipFree(p);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s = Slot();
+}
+
+// allocate one in-flight slot (stream + activation workspace for max_batch triplets)
+int alloc_slot(davo_ctx* c, Slot* s) {
+    const size_t NB = 2 * (size_t)c->max_batch;
+    HIP_TRY(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 7; ++i)
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_act[i]), NB * c->act_floats_per_img[i] * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_packed), NB * (size_t)c->H * c->W * 10 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_partial), (size_t)c->max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_tab), (size_t)c->max_batch * 3 * NCLS * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_pose_partial), NB * 2 * PH_SPLIT * 3 * sizeof(float)));
+    HIP_TRY(c, hipMemset(s->d_partial, 0, (size_t)c->max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
+    return DAVO_OK;
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const davo_variant* v) {
+    if (!out || !v) return DAVO_ERR_INVALID;
+    *out = nullptr;
+    davo_ctx* c = new davo_ctx();
+    *out = c;                                   // returned even on failure so the message is readable
+    c->device = device; c->H = H; c->W = W; c->max_batch = max_batch;
+    c->v = Variant{v->cin_per_frame, v->cnv6_out, v->se_act, v->norm_flow, v->abs_mode, v->att_source,
+                   v->mask_rgb, v->mask_info};
+    if (H < 16 || W < 16 || H % 4 || W % 4) return fail(c, DAVO_ERR_INVALID, "H and W must be multiples of 4 and >= 16 (got %dx%d)", H, W);
+    if (max_batch < 1) return fail(c, DAVO_ERR_INVALID, "max_batch must be >= 1");
+    if (v->cin_per_frame != 5 && v->cin_per_frame != 3) return fail(c, DAVO_ERR_INVALID, "cin_per_frame must be 3 or 5");
+    if (ilog2_exact(v->cnv6_out) < 5 || v->cnv6_out > 256) return fail(c, DAVO_ERR_INVALID, "cnv6_out must be 32, 64, 128 or 256");
+    if (v->se_act < 0 || v->se_act > 2 || v->abs_mode < 0 || v->abs_mode > 3 || v->att_source < 0 || v->att_source > 3)
+        return fail(c, DAVO_ERR_INVALID, "variant field out of range");
+    int ndev = 0;
+    HIP_TRY(c, hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(c, DAVO_ERR_INVALID, "device %d not present (%d visible)", device, ndev);
+    HIP_TRY(c, hipSetDevice(device));
+    c->needed = needed_names(c->v);
+
+    c->H1 = (H + 1) / 2; c->W1 = (W + 1) / 2;
+    c->H2 = (c->H1 + 1) / 2; c->W2 = (c->W1 + 1) / 2;
+    c->H3 = (c->H2 + 1) / 2; c->W3 = (c->W2 + 1) / 2;
+    const int c6 = c->v.cnv6_out;
+    init_layer(c->L[0], "cnv1", 7, 2, 1, 8, 16, 1);
+    init_layer(c->L[1], "cnv2", 5, 2, 1, 16, 32, 1);
+    init_layer(c->L[2], "cnv3", 3, 1, 2, 32, 64, 1);
+    init_layer(c->L[3], "cnv4", 3, 1, 4, 64, 128, 1);
+    init_layer(c->L[4], "cnv5", 3, 1, 8, 128, 256, 1);
+    init_layer(c->L[5], "cnv6", 3, 1, 2, 256, 2 * c6, 1);
+    init_layer(c->L[6], "cnv7", 3, 2, 1, c6, 256, 2);
+
+    const int ch[7] = {16, 32, 64, 128, 256, 2 * c6, 512};
+    const size_t px[7] = {(size_t)c->H1 * c->W1, (size_t)c->H2 * c->W2, (size_t)c->H2 * c->W2, (size_t)c->H2 * c->W2,
+                          (size_t)c->H2 * c->W2, (size_t)c->H2 * c->W2, (size_t)c->H3 * c->W3};
+    for (int i = 0; i < 7; ++i) {
+        c->act_ch[i] = ch[i];
+        c->act_floats_per_img[i] = px[i] * ch[i];
+    }
+    c->slots.resize(1);
+    { int rc = alloc_slot(c, &c->slots[0]); if (rc) return rc; }
+    c->own_stream = c->slots[0].stream;
+    activate_slot(c, 0);
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_zeros), 256));
+    HIP_TRY(c, hipMemset(c->d_zeros, 0, 256));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_range), 8 * sizeof(unsigned)));
+    HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned)));
+    return DAVO_OK;
+}
+
+int davo_load_weight(davo_ctx* c, const char* tf_name, const float* data, const int64_t* shape, int ndim) {
+    if (!c || !tf_name || !data || !shape || ndim < 1 || ndim > 4) return fail(c, DAVO_ERR_INVALID, "bad argument to davo_load_weight");
+    std::vector<int64_t> want;
+    if (!expected_shape(c, tf_name, &want)) return fail(c, DAVO_ERR_INVALID, "unknown variable `%s'", tf_name);
+    bool listed = false;
+    for (auto& n : c->needed) listed |= (n == tf_name);
+    if (!listed) return fail(c, DAVO_ERR_INVALID, "variable `%s' is not part of this variant", tf_name);
+    std::vector<int64_t> got(shape, shape + ndim);
+    if (got != want) {
+        std::string g, w;
+        for (auto d : got) g += std::to_string(d) + ",";
+        for (auto d : want) w += std::to_string(d) + ",";
+        return fail(c, DAVO_ERR_INVALID, "`%s': shape [%s] does not match expected [%s]", tf_name, g.c_str(), w.c_str());
+    }
+    size_t n = 1;
+    for (auto d : got) n *= (size_t)d;
+    HostTensor& t = c->weights[tf_name];
+    t.shape = got;
+    t.data.assign(data, data + n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = upload(c, t.data, &t.dev);
+    if (rc) return rc;
+    c->packed_ready = false;
+    c->packed_h_ready = false;
+    return DAVO_OK;
+}
+
+int davo_weights_missing(davo_ctx* c) {
+    if (!c) return DAVO_ERR_INVALID;
+    std::string names;
+    const int n = missing_weights(c, &names);
+    if (n) c->err = "weights not loaded: " + names;
+    return n;
+}
+
+// read the range record of the f16x3 forwards issued since the last check, reset it, and judge it
+// (forward.hip: check_range).  Called with every stream of the context idle.
+static int consume_range_record(davo_ctx* c) {
+    if (!c->range_dirty || !c->d_range) return DAVO_OK;
+    unsigned raw[6];
+    HIP_TRY(c, hipMemcpy(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned)));
+    c->range_dirty = false;
+    return check_range(c, raw);
+}
+
+int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg,
+                        void* d_pose, float* elapsed_ms) {
+    if (!c) return DAVO_ERR_INVALID;
+    // rotate through the in-flight slots: this batch runs on its own stream and workspace
+    activate_slot(c, c->next_slot);
+    c->next_slot = (c->next_slot + 1) % c->inflight;
+    if (!elapsed_ms) return forward_device(c, B, d_img, d_flow, d_seg, d_pose);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = DAVO_OK;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == DAVO_OK) rc = fail(c, DAVO_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    if (hip_ok(hipEventCreate(&e0), "hipEventCreate") && hip_ok(hipEventCreate(&e1), "hipEventCreate") &&
+        hip_ok(hipEventRecord(e0, c->stream), "hipEventRecord")) {
+        rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
+        if (rc == DAVO_OK && hip_ok(hipEventRecord(e1, c->stream), "hipEventRecord") &&
+            hip_ok(hipEventSynchronize(e1), "hipEventSynchronize"))
+            hip_ok(hipEventElapsedTime(elapsed_ms, e0, e1), "hipEventElapsedTime");
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    // the timed form is synchronous, so it can judge the range record of its own batch
+    if (rc == DAVO_OK && c->inflight == 1) rc = consume_range_record(c);
+    return rc;
+}
+
+int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, const float* seg, float* pose_out) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (!img || !flow || !seg || !pose_out) return fail(c, DAVO_ERR_INVALID, "null host pointer");
+    if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = sync_all_slots(c); if (rc) return rc; }       // the host path owns the single staging buffer set
+    activate_slot(c, 0);
+    const size_t HW = (size_t)c->H * c->W;
+    const size_t nb_img = HW * 9, nb_flow = HW * 8 * sizeof(float), nb_seg = HW * 3 * sizeof(float);
+    if (!c->s_img) {
+        HIP_TRY(c, hipMalloc(&c->s_img, nb_img * c->max_batch));
+        HIP_TRY(c, hipMalloc(&c->s_flow, nb_flow * c->max_batch));
+        HIP_TRY(c, hipMalloc(&c->s_seg, nb_seg * c->max_batch));
+        HIP_TRY(c, hipMalloc(&c->s_pose, (size_t)c->max_batch * 12 * sizeof(float)));
+    }
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    { int rc = consume_range_record(c); if (rc) return rc; }    // device-path batches issued before this call
+    HIP_TRY(c, hipMemsetAsync(c->d_range, 0, 8 * sizeof(unsigned), c->stream));      // the monitor covers this call
+    // Sub-batches: the copy of chunk i+1 (copy_stream) overlaps the kernels of chunk i (compute stream).
+    // Results do not depend on the split (windows are independent; tests/test_hip_parity.py batch invariance).
+    // Only flow planes 0 and 1 are read by the path (davo.py:978-982), so only those cross PCIe.
+    const int chunk = (c->host_chunk > 0 && B >= 2 * c->host_chunk) ? c->host_chunk : B;
+    const int nchunks = (B + chunk - 1) / chunk;
+    while ((int)c->copy_done.size() < nchunks) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->copy_done.push_back(e);
+    }
+    for (int i = 0; i < nchunks; ++i) {
+        const int b0 = i * chunk, nb = std::min(chunk, B - b0);
+        uint8_t* di = (uint8_t*)c->s_img + nb_img * b0;
+        uint8_t* df = (uint8_t*)c->s_flow + nb_flow * b0;
+        uint8_t* ds = (uint8_t*)c->s_seg + nb_seg * b0;
+        HIP_TRY(c, hipMemcpyAsync(di, img + nb_img * b0, nb_img * nb, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpy2DAsync(df, nb_flow, (const uint8_t*)flow + nb_flow * b0, nb_flow, nb_flow / 2, nb,
+                                    hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(ds, (const uint8_t*)seg + nb_seg * b0, nb_seg * nb, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(c->copy_done[i], c->copy_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_done[i], 0));
+        int rc = forward_device(c, nb, di, (const float*)df, (const float*)ds, (float*)c->s_pose + (size_t)b0 * 12);
+        if (rc) return rc;
+    }
+    HIP_TRY(c, hipMemcpyAsync(pose_out, c->s_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    unsigned raw[6];
+    HIP_TRY(c, hipMemcpyAsync(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned)));
+    c->range_dirty = false;
+    return c->last_precision == 1 ? check_range(c, raw) : DAVO_OK;
+}
+
+int davo_activation_range(davo_ctx* c, float* max_abs, int* shifts, int reset) {
+    if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    unsigned raw[6];
+    HIP_TRY(c, hipMemcpy(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) {
+        float v;
+        memcpy(&v, &raw[i], sizeof v);
+        if (max_abs) max_abs[i] = ldexpf(v, -c->act_shift[i]);
+        if (shifts) shifts[i] = c->act_shift[i];
+    }
+    if (reset) { HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned))); c->range_dirty = false; }
+    return DAVO_OK;
+}
+
+int davo_set_activation_shifts(davo_ctx* c, const int* shifts) {
+    if (!c) return DAVO_ERR_INVALID;
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    for (int i = 0; i < 6; ++i) {
+        const int s = shifts ? shifts[i] : 0;
+        if (s < -60 || s > 60) return fail(c, DAVO_ERR_INVALID, "activation shift %d outside [-60,60]", s);
+        c->act_shift[i] = s;
+    }
+    return DAVO_OK;
+}
+
+int davo_calibrate(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, int* shifts_out) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
+    if (!d_img || !d_flow || !d_seg) return fail(c, DAVO_ERR_INVALID, "null device pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    activate_slot(c, 0);
+    float* d_pose = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_pose), (size_t)B * 12 * sizeof(float)));
+    int rc = DAVO_OK;
+    const int save_precision = c->precision, save_impl = c->impl;
+    c->precision = 1; c->impl = 0;
+    // A layer computed from badly ranged inputs still has about the right magnitude, so each pass fixes at
+    // least the first badly ranged layer exactly and the later ones to within a few powers of two.
+    for (int pass = 0; pass < 8 && rc == DAVO_OK; ++pass) {
+        if (hipMemset(c->d_range, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = fail(c, DAVO_ERR_HIP, "hipMemset failed"); break; }
+        rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
+        if (rc) break;
+        unsigned raw[6];
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(c, DAVO_ERR_HIP, "reading the activation ranges failed");
+            break;
+        }
+        bool changed = false;
+        for (int i = 0; i < 6; ++i) {
+            float v;
+            memcpy(&v, &raw[i], sizeof v);
+            int delta = 0;
+            if (!std::isfinite(v)) delta = -32;
+            else if (v > 0.f) { int e; (void)frexpf(v, &e); delta = 10 - e; }        // stored max -> [2^9, 2^10): 64x headroom
+            int ns = c->act_shift[i] + delta;
+            ns = ns < -60 ? -60 : (ns > 60 ? 60 : ns);
+            if (ns != c->act_shift[i]) { c->act_shift[i] = ns; changed = true; }
+        }
+        if (!changed) break;
+    }
+    c->precision = save_precision; c->impl = save_impl;
+    (void)hipMemset(c->d_range, 0, 8 * sizeof(unsigned));
+    c->range_dirty = false;
+    (void)hipFree(d_pose);
+    if (rc == DAVO_OK && shifts_out) for (int i = 0; i < 6; ++i) shifts_out[i] = c->act_shift[i];
+    return rc;
+}
+
+const char* davo_last_error(const davo_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+void davo_destroy(davo_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)sync_all_slots(c);
+    comm_release(c);
+    for (auto& kv : c->weights) if (kv.second.dev) (void)hipFree(kv.second.dev);
+    for (auto& L : c->L) {
+        if (L.d_w) (void)hipFree(L.d_w);
+        if (L.d_b) (void)hipFree(L.d_b);
+        if (L.d_wh) (void)hipFree(L.d_wh);
+        if (L.d_bh) (void)hipFree(L.d_bh);
+    }
+    for (auto e : c->copy_done) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    void* misc[] = {c->d_range, c->d_pose_tiles, c->d_w1patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
+    for (auto p : misc) if (p) (void)hipFree(p);
+    for (auto& pe : c->prof_entries)
+        for (auto& ab : pe.pending) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto& sl : c->slots) free_slot(sl);
+    delete c;
+}
+
+int davo_host_alloc(int device, size_t bytes, void** out) {
+    if (!out || bytes == 0) return DAVO_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return DAVO_ERR_HIP;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? DAVO_OK : DAVO_ERR_HIP;
+}
+int davo_host_free(void* p) { return hipHostFree(p) == hipSuccess ? DAVO_OK : DAVO_ERR_HIP; }
+
+int davo_device_malloc(davo_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMalloc(out, bytes));
+    return DAVO_OK;
+}
+int davo_device_free(davo_ctx* c, void* p) {
+    if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipFree(p));
+    return DAVO_OK;
+}
+int davo_memcpy_h2d(davo_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DAVO_OK;
+}
+int davo_memcpy_d2h(davo_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DAVO_OK;
+}
+int davo_synchronize(davo_ctx* c) {
+    if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    // f16x3: the batches davo_forward_device issued since the last synchronize are judged here (the asynchronous
+    // entry point cannot know its own result): DAVO_ERR_RANGE = some layer left the fp16-pair storage range
+    return consume_range_record(c);
+}
+int davo_set_stream(davo_ctx* c, void* hip_stream) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (hip_stream && c->inflight > 1) return fail(c, DAVO_ERR_INVALID, "a caller-owned stream needs davo_set_inflight(ctx, 1)");
+    c->user_stream = hip_stream != nullptr;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return DAVO_OK;
+}
+
+int davo_profile_enable(davo_ctx* c, int on) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (!on && c->prof) { int rc = prof_collect(c); if (rc) return rc; }
+    c->prof = on != 0;
+    c->prof_dominant_only = on == 2;
+    return DAVO_OK;
+}
+int davo_profile_reset(davo_ctx* c) {
+    if (!c) return DAVO_ERR_INVALID;
+    int rc = prof_collect(c);
+    if (rc) return rc;
+    for (auto& pe : c->prof_entries) { pe.launches = 0; pe.total_ms = 0.0; }
+    return DAVO_OK;
+}
+int davo_profile_entry(davo_ctx* c, int i, char* name, int name_len, int* launches, double* total_ms) {
+    if (!c) return DAVO_ERR_INVALID;
+    int rc = prof_collect(c);
+    if (rc) return rc;
+    if (i < 0 || i >= (int)c->prof_entries.size()) return DAVO_ERR_INVALID;
+    const ProfEntry& pe = c->prof_entries[i];
+    if (name && name_len > 0) { strncpy(name, pe.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    if (launches) *launches = pe.launches;
+    if (total_ms) *total_ms = pe.total_ms;
+    return DAVO_OK;
+}
+
+int davo_last_plan(davo_ctx* c, int layer, int launch, int* mtiles, int* bn) {
+    if (!c || layer < 0 || layer > 6 || launch < 0 || launch > 1) return DAVO_ERR_INVALID;
+    const int v = c->last_plan[layer][launch];
+    if (mtiles) *mtiles = v / 1000;
+    if (bn) *bn = v % 1000;
+    return DAVO_OK;
+}
+
+int davo_set_inflight(davo_ctx* c, int n) {
+    if (!c || n < 1 || n > 4) return fail(c, DAVO_ERR_INVALID, "inflight must be 1..4");
+    if (n > 1 && c->user_stream) return fail(c, DAVO_ERR_INVALID, "in-flight slots use the context's own streams: clear davo_set_stream first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    while ((int)c->slots.size() < n) {
+        c->slots.emplace_back();
+        int rc = alloc_slot(c, &c->slots.back());
+        if (rc) return rc;
+    }
+    c->inflight = n;
+    c->next_slot = 0;
+    return DAVO_OK;
+}
+
+int davo_set_option(davo_ctx* c, const char* key, int value) {
+    if (!c || !key) return DAVO_ERR_INVALID;
+    const std::string k = key;
+    if (k == "fuse_pose") c->opt_fuse_pose = value != 0;
+    else if (k == "fuse_pack") c->opt_fuse_pack = value != 0;
+    else if (k == "host_chunk") { if (value < 0) return fail(c, DAVO_ERR_INVALID, "host_chunk must be >= 0"); c->host_chunk = value; }
+    else return fail(c, DAVO_ERR_INVALID, "unknown option `%s'", key);
+    return DAVO_OK;
+}
+
+int davo_set_precision(davo_ctx* c, int precision) {
+    if (!c || (precision != 0 && precision != 1)) return fail(c, DAVO_ERR_INVALID, "precision must be 0 (f32) or 1 (f16x3)");
+    c->precision = precision;
+    return DAVO_OK;
+}
+
+int davo_set_impl(davo_ctx* c, int impl) {
+    if (!c || (impl != 0 && impl != 1)) return fail(c, DAVO_ERR_INVALID, "impl must be 0 (mfma) or 1 (direct)");
+    c->impl = impl;
+    return DAVO_OK;
+}
+
+int davo_debug_read(davo_ctx* c, const char* tensor, float* host_out, size_t n_floats) {
+    if (!c || !tensor || !host_out) return DAVO_ERR_INVALID;
+    if (c->last_B < 1) return fail(c, DAVO_ERR_NOT_READY, "no forward has run yet");
+    const size_t NB = 2 * (size_t)c->last_B;
+    const float* src = nullptr;
+    size_t n = 0;
+    const std::string t = tensor;
+    if (t == "att_table") { src = c->d_tab; n = (size_t)c->last_B * 3 * NCLS; }
+    else if (t == "packed") {
+        if (!c->packed_valid) {          // fused path: materialise the packed tensor on demand from the last inputs
+            HIP_TRY(c, launch_mask_pack(16, static_cast<const uint8_t*>(c->last_img), static_cast<const float*>(c->last_flow),
+                                        static_cast<const float*>(c->last_seg), c->d_tab, c->v, c->last_B, c->H, c->W, c->d_packed, c->stream));
+            c->packed_valid = true;
+        }
+        src = c->d_packed; n = NB * c->H * c->W * c->packed_ld;
+    }
+    else {
+        const char* names[7] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6", "cnv7"};
+        for (int i = 0; i < 7; ++i)
+            if (t == names[i]) { src = c->d_act[i]; n = NB * c->act_floats_per_img[i]; }
+    }
+    if (t == "cnv7" && !c->cnv7_valid)
+        return fail(c, DAVO_ERR_NOT_READY, "cnv7 was not materialised: the pose head ran fused (davo_set_option(ctx, \"fuse_pose\", 0))");
+    if (!src) return fail(c, DAVO_ERR_INVALID, "unknown tensor `%s'", tensor);
+    if (n != n_floats) return fail(c, DAVO_ERR_INVALID, "`%s' holds %zu floats, caller asked for %zu", tensor, n, n_floats);
+    int rc = davo_memcpy_d2h(c, host_out, src, n * sizeof(float));
+    if (rc) return rc;
+    const bool split = c->last_precision == 1 && t != "att_table" && t != "cnv7";
+    if (split) {       // split-fp16 blocked -> plain float32 NHWC
+        int ch = 8;
+        const char* names[6] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6"};
+        for (int i = 0; i < 6; ++i) if (t == names[i]) ch = c->act_ch[i];
+        const int cb = ch < 32 ? ch : 32;
+        int shift = 0;
+        for (int i = 0; i < 6; ++i) if (t == names[i]) shift = c->act_shift[i];
+        std::vector<float> tmp(ch);
+        const size_t npix = n / ch;
+        for (size_t px = 0; px < npix; ++px) {
+            const _Float16* raw = reinterpret_cast<const _Float16*>(host_out + px * ch);
+            for (int k = 0; k < ch; ++k) {
+                const _Float16* blk = raw + (size_t)(k / cb) * cb * 2;
+                tmp[k] = ldexpf((float)blk[k % cb] + (float)blk[cb + k % cb], -shift);
+            }
+            memcpy(host_out + px * ch, tmp.data(), ch * sizeof(float));
+        }
+    }
+    return DAVO_OK;
+}
+
+int davo_plan_layer(int M, int npad, int groups, int* rows, int* tile_bm, int* tile_bn) {
+    if (M < 1 || npad < 32 || npad % 32 || groups < 1 || !rows || !tile_bm || !tile_bn) return DAVO_ERR_INVALID;
+    const std::vector<LaunchH> plan = plan_layer_h3(M, npad, groups, -1);
+    if (plan.empty() || plan.size() > 2) return DAVO_ERR_INVALID;
+    for (size_t i = 0; i < plan.size(); ++i) {
+        const TileShape ts = tile_shape(plan[i].tile);
+        rows[i] = plan[i].rows; tile_bm[i] = ts.bm; tile_bn[i] = ts.bn;
+    }
+    return (int)plan.size();
+}
+
+int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, const float* w, int k, int Cout,
+                     const float* bias, int stride, int rate, int relu, int precision, float* y, char* err, int err_len) {
+    auto bad = [&](const char* m, int code) {
+        if (err && err_len > 0) { strncpy(err, m, err_len - 1); err[err_len - 1] = 0; }
+        return code;
+    };
+    const int cl = ilog2_exact(Cin);
+    if (!x || !w || !bias || !y) return bad("null pointer", DAVO_ERR_INVALID);
+    if (cl < 2) return bad("Cin must be a power of two >= 4", DAVO_ERR_INVALID);
+    if (precision == 1 && cl < 3) return bad("f16x3 needs Cin >= 8", DAVO_ERR_INVALID);
+    if (!(k == 1 || k == 3 || k == 5 || k == 7) || !(stride == 1 || stride == 2) || rate < 1)
+        return bad("k in {1,3,5,7}, stride in {1,2}, rate >= 1", DAVO_ERR_INVALID);
+    if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed", DAVO_ERR_HIP);
+    ConvLayer L;
+    init_layer(L, "conv", k, stride, rate, Cin, Cout, 1);
+    int Ho, Wo, pt, pl;
+    same_pad(H, k, stride, rate, &Ho, &pt);
+    same_pad(W, k, stride, rate, &Wo, &pl);
+    const size_t nx = (size_t)N * H * W * Cin, ny = (size_t)N * Ho * Wo * Cout;
+    std::vector<float> bp(precision == 1 ? L.npad_h : L.npad, 0.f);
+    memcpy(bp.data(), bias, Cout * sizeof(float));
+    std::vector<float> wp;
+    std::vector<_Float16> wph, xh;
+    const void *hx = x, *hw = nullptr;
+    size_t wbytes = 0;
+    if (precision == 1) {
+        wph.assign((size_t)L.npad_h * L.nchunks_h * 64, (_Float16)0.0f);
+        L.wscale = weight_prescale(w, (size_t)k * k * Cin * Cout);
+        pack_conv_weights_h3(w, k, Cin, Cout, nullptr, Cin, L.cb_log2, L.tpc_log2, L.cpb, L.nchunks_h, L.wscale, wph.data());
+        hw = wph.data(); wbytes = wph.size() * sizeof(_Float16);
+        const int cb = 1 << L.cb_log2;                       // float32 NHWC -> split-fp16 blocked
+        xh.resize(nx * 2);
+        for (size_t px = 0; px < nx / Cin; ++px)
+            for (int ch = 0; ch < Cin; ++ch) {
+                _Float16* blk = xh.data() + px * Cin * 2 + (size_t)(ch / cb) * cb * 2;
+                split_f16(x[px * Cin + ch], blk + ch % cb, blk + cb + ch % cb);
+            }
+        hx = xh.data();
+    } else {
+        wp.assign((size_t)L.npad * L.kpad, 0.f);
+        pack_conv_weights(w, k, Cin, Cout, nullptr, Cin, L.npad, L.kpad, wp.data());
+        hw = wp.data(); wbytes = wp.size() * sizeof(float);
+    }
+    void *dx = nullptr, *dw = nullptr, *db = nullptr, *dy = nullptr, *dz = nullptr;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    chk(hipMalloc(&dx, nx * 4)); chk(hipMalloc(&dw, wbytes));
+    chk(hipMalloc(&db, bp.size() * 4)); chk(hipMalloc(&dy, ny * 4));
+    chk(hipMalloc(&dz, 256));
+    if (e == hipSuccess) {
+        chk(hipMemset(dz, 0, 256));
+        chk(hipMemcpy(dx, hx, nx * 4, hipMemcpyHostToDevice));
+        chk(hipMemcpy(dw, hw, wbytes, hipMemcpyHostToDevice));
+        chk(hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+        if (precision == 1) {
+            const int tile = Cout <= 32 ? TILE_128x32 : Cout <= 64 ? TILE_256x64 : Cout <= 128 ? TILE_256x128 : TILE_128x256;
+            const TileShape ts = tile_shape(tile);
+            ConvParamsH p{};
+            p.x = static_cast<const uint8_t*>(dx); p.w = static_cast<const uint8_t*>(dw);
+            p.bias = static_cast<const float*>(db); p.y = static_cast<uint8_t*>(dy);
+            p.zeros = static_cast<const uint8_t*>(dz);
+            p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.x_pix_bytes = (long)Cin * 4;
+            p.cb_log2 = L.cb_log2; p.tpc_log2 = L.tpc_log2; p.cpb = L.cpb; p.nchunks = L.nchunks_h;
+            p.w_row_bytes = (long)L.nchunks_h * 128; p.y_mode = 0; p.y_ld = Cout; p.Cout = Cout;
+            p.pad_t = pt; p.pad_l = pl; p.rate = rate; p.M = N * Ho * Wo; p.ntaps = k * k;
+            p.ntiles_n = L.npad_h / ts.bn; p.relu = relu; p.out_scale = 1.0f / L.wscale; p.bias_scale = L.wscale; p.range = nullptr;
+            dim3 grid((p.M + ts.bm - 1) / ts.bm * p.ntiles_n, 1);
+            const hipError_t le = launch_h3_generic(k, stride, tile, p, grid, nullptr);
+            chk(le);
+        } else {
+            ConvParams p{};
+            p.x = static_cast<const float*>(dx); p.w = static_cast<const float*>(dw);
+            p.bias = static_cast<const float*>(db); p.y = static_cast<float*>(dy);
+            p.zeros = static_cast<const float*>(dz);
+            p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.cin_log2 = cl; p.x_ld = Cin; p.y_ld = Cout;
+            p.Cout = Cout; p.pad_t = pt; p.pad_l = pl; p.rate = rate; p.M = N * Ho * Wo;
+            p.nchunks = L.nchunks; p.Kpad = L.kpad; p.ntaps = k * k; p.ntiles_n = L.npad / L.BN; p.relu = relu;
+            dim3 grid((p.M + BM - 1) / BM * p.ntiles_n, 1);
+            chk(launch_conv(k, stride, L.BN, p, grid, nullptr));
+        }
+        chk(hipDeviceSynchronize());
+        chk(hipMemcpy(y, dy, ny * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dz); (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dy);
+    if (e != hipSuccess) return bad(hipGetErrorString(e), DAVO_ERR_HIP);
+    return DAVO_OK;
+}
+
+}  // extern "C"

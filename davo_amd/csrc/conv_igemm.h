@@ -23,44 +23,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "params.h"
+
 namespace davo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvParams {
-    const float* x;       // input activation, pixel-major NHWC
-    const float* w;       // packed weights [Npad][Kpad]
-    const float* bias;    // [Npad]
-    float* y;             // output activation
-    const float* zeros;   // >= 16 bytes of zeros: what a padded (out-of-image) tap reads
-    int Hin, Win, Hout, Wout;
-    int cin_log2;         // Cin = 1 << cin_log2 (channels per tap in the packed k order)
-    int x_ld, x_coff;     // floats per input pixel, first channel used
-    int y_ld, y_coff;     // floats per output pixel, first channel written
-    int Cout;             // valid output channels (per group)
-    int pad_t, pad_l, rate;
-    int M;                // images * Hout * Wout
-    int nchunks, Kpad, ntaps;
-    int ntiles_n;
-    int mtile0;           // first 128-row M tile of this launch (a layer may be split in two launches)
-    int relu;
-    // grouped launch (blockIdx.y = group): per-group strides
-    int g_x_coff, g_y_coff;
-    long g_w, g_bias;
-};
-
-constexpr int BM = 128;
-constexpr int BK = 32;
-constexpr int LDK = 36;          // padded LDS row (floats)
-
-template <int BN> struct Tile {
-    static constexpr int WN = BN >= 64 ? 2 : 1;    // waves along N
-    static constexpr int WM = 4 / WN;              // waves along M
-    static constexpr int TM = BM / WM / 32;        // 32x32 MFMA tiles per wave along M
-    static constexpr int TN = BN / WN / 32;
-    static constexpr int NB_LOADS = BN / 32;       // float4 weight loads per thread per chunk
-    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDK * 4;
-};
 
 // XCD-aware, bijective remap of the linear workgroup id: workgroups b, b+8, b+16, ... share an
 // XCD (and its 4 MiB L2), so give each XCD a contiguous run of tiles = neighbouring pixels of

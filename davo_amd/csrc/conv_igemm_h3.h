@@ -36,6 +36,14 @@
 
 #include "conv_igemm.h"
 
+// measurement-only switches of the kernels (ConvParamsH::dbg) exist in a -DDAVO_TUNING build only; the product
+// library compiles them out
+#ifdef DAVO_TUNING
+#define H3_DBG(bit_) ((p.dbg & (bit_)) != 0)
+#else
+#define H3_DBG(bit_) false
+#endif
+
 #ifndef DAVO_H3_NDG8
 #define DAVO_H3_NDG8 2          // 8-group chunks: matrix groups that carry the next chunk's DMA (2: four loads each, groups 1-2; 4 measured 0.5 % slower)
 #endif
@@ -44,57 +52,6 @@ namespace davo {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvParamsH {
-    const uint8_t* x;       // split-fp16 blocked activation
-    const uint8_t* w;       // packed weights: [Npad][nchunks][32 hi | 32 lo] halves (128 B per chunk)
-    const float* bias;      // [Npad]
-    uint8_t* y;             // output: float32 NHWC (y_mode 0) or split-fp16 blocked (y_mode 1)
-    const uint8_t* zeros;   // >= 16 zero bytes: what a padded (out-of-image) tap reads
-    int Hin, Win, Hout, Wout;
-    long x_pix_bytes;       // bytes per input pixel (all channels of the tensor x 4)
-    int x_boff;             // byte offset inside a pixel of the first channel block used
-    int cb_log2;            // CB = channels per block = min(Cin, 32)
-    int tpc_log2;           // taps per chunk = 32 / CB
-    int cpb;                // chunks per channel block = ceil(ntaps / taps per chunk)
-    int nchunks;
-    long w_row_bytes;       // nchunks * 128
-    int y_mode, y_ld, y_coff, Cout;
-    int pad_t, pad_l, rate;
-    int M, ntaps, ntiles_n, mtile0, relu;
-    int g_x_boff, g_y_coff;
-    long g_w, g_bias;
-    float out_scale;        // 2^(shift_out - shift_in) / (power of two the layer's weights were multiplied by)
-    float bias_scale;       // accumulator init = bias * bias_scale (weight scale * 2^shift_in; a power of two)
-    unsigned* range;        // y_mode 1: atomicMax of the stored (scaled) activations' bit patterns; may be null
-    // y_mode 2 (cnv7 only): the pose head is fused into the epilogue, nothing is stored but this tile's
-    // contribution to sum_pixels sum_channels relu(cnv7) * Wpred[c][k] for the (at most two) images it touches
-    const float* pose_w;    // [groups][256][3] pred kernels
-    float* pose_partial;    // [groups][pose_mt][ntiles_n][2 image slots][3]
-    int pose_P, pose_mt;    // output pixels per image (>= tile height), M tiles in the launch
-    int dbg;                // measurement only (DAVO_DBG; results are wrong with any bit set): 1 DMA reads the zero line,
-                            // 2 no matrix phase, 4 no wave-half stagger (32x32x16 form), 32 no epilogue, 64 stores fold onto 256 tiles
-};
-
-constexpr int LDB = 144;        // LDS row: 128 data bytes + 16 pad (conflict-free b128 fragment reads)
-
-template <int WM, int WN, int TM, int TN, int NSTG = 2> struct TileH {
-    static constexpr int THREADS = WM * WN * 64;
-    static constexpr int BMH = WM * TM * 32;
-    static constexpr int BNH = WN * TN * 32;
-    static constexpr int A_LOADS = BMH * 8 / THREADS;
-    static constexpr int B_LOADS = BNH * 8 / THREADS;
-    static constexpr int ROWS_PER_PASS = THREADS / 8;
-    static constexpr int LDS_BYTES = 2 * (BMH + BNH) * LDB;          // register-staged: padded rows
-#ifndef DAVO_H3_STAGES
-#define DAVO_H3_STAGES 2
-#endif
-    // LDS ring slots: 2; the 128x128 tile of a remainder launch (one workgroup per CU, nothing else to hide the DMA
-    // latency behind) takes 3
-    static constexpr int DMA_STAGES = DAVO_H3_STAGES == 2 ? NSTG : DAVO_H3_STAGES;
-    static constexpr int LDS_BYTES_DMA = DMA_STAGES * (BMH + BNH) * 128;   // LDS-DMA ring: linear rows, XOR-swizzled units
-    static_assert(A_LOADS >= 1 && A_LOADS <= 4 && B_LOADS >= 1 && B_LOADS <= 4, "staging shape");
-};
 
 typedef __attribute__((address_space(3))) const uint8_t lds_u8_t;
 // 32-bit LDS address of a pointer into shared memory (operand of ds_read_*)
@@ -447,17 +404,17 @@ void conv_igemm_h3(ConvParamsH p) {
                 // MFMAs instead of in front of them, and every load still has half a chunk to land
                 // (the last chunk has nothing to prefetch: its slots re-load the last weight chunk and zero rows
                 // into the idle ring slot instead of branching around the interleaved code)
-                const bool dma_on = more && !(p.dbg & 1);
-                if (!(p.dbg & 2)) H3_CHUNK16(slot)
+                const bool dma_on = more && !H3_DBG(1);
+                if (!H3_DBG(2)) H3_CHUNK16(slot)
                 else if (dma_on) H3_DMA_CHUNK(q + NST - 1, nslot)
             } else {
                 // Stagger (32x32x16 form): the two waves that share a SIMD would otherwise run the same phases in
                 // lockstep; the second half of the workgroup issues its DMA after its first k-step
-                const bool late_dma = (p.dbg & 4) ? false : (WM * WN >= 8 && wave_u >= (WM * WN) / 2);
-                if (more && !late_dma && !(p.dbg & 1)) H3_DMA_CHUNK(q + NST - 1, nslot)
-                if (!(p.dbg & 2)) H3_STEP32(slot, 0)
-                if (more && late_dma && !(p.dbg & 1)) H3_DMA_CHUNK(q + NST - 1, nslot)
-                if (!(p.dbg & 2)) H3_STEP32(slot, 1)
+                const bool late_dma = H3_DBG(4) ? false : (WM * WN >= 8 && wave_u >= (WM * WN) / 2);
+                if (more && !late_dma && !H3_DBG(1)) H3_DMA_CHUNK(q + NST - 1, nslot)
+                if (!H3_DBG(2)) H3_STEP32(slot, 0)
+                if (more && late_dma && !H3_DBG(1)) H3_DMA_CHUNK(q + NST - 1, nslot)
+                if (!H3_DBG(2)) H3_STEP32(slot, 1)
             }
             if (q + 1 < p.nchunks) {
                 // M16: the filler DMA keeps the count of younger instructions constant, so the counted wait always holds
@@ -470,7 +427,7 @@ void conv_igemm_h3(ConvParamsH p) {
         if constexpr (M16) __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // the last chunk's filler DMA must land before LDS is reused
     }
 
-    if (p.dbg & 32) return;                                       // measurement only: no epilogue
+    if (H3_DBG(32)) return;                                       // measurement only: no epilogue
     // ---- epilogues.  Both accumulator layouts are walked through the same three helpers:
     //   column group jj -> column inside the wave tile; (row group ii, register r) -> row inside the wave tile
     constexpr int NCG = M16 ? 2 * TN : TN, NRG = M16 ? 2 * TM : TM, NREG = M16 ? 4 : 16;
@@ -540,7 +497,7 @@ void conv_igemm_h3(ConvParamsH p) {
     const int ocb_log2 = p.y_ld >= 32 ? 5 : (p.y_ld == 16 ? 4 : 3);
     const int ocb = 1 << ocb_log2;
     float vmax = 0.f;                                                // largest |stored value| of this lane (range monitor)
-    const int mt_store = (p.dbg & 64) ? (mtile & 255) : mtile;       // 64: measurement only, stores fold onto 256 tiles
+    const int mt_store = H3_DBG(64) ? (mtile & 255) : mtile;       // 64: measurement only, stores fold onto 256 tiles
 
     // Split store, interior tile (every row < M, every column < Cout: all but the last tile row of a launch).
     // The general loop below costs ~35 instructions and three branches per value (64-bit address products, bounds
@@ -630,6 +587,7 @@ void conv_igemm_h3(ConvParamsH p) {
     }
 }
 
+#undef H3_DBG
 #undef H3_DMA_A
 #undef H3_DMA_B
 #undef H3_DMA_CHUNK

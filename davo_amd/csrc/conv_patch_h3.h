@@ -25,39 +25,6 @@
 
 namespace davo {
 
-
-namespace cp1 {
-constexpr int KS = 7, TH = 8, TW = 16;                 // filter, output tile
-constexpr int PH = 2 * TH + KS - 2, PW = 2 * TW + KS - 2;      // 21 x 37 input pixels
-constexpr int UNITS = 32;                              // 16-byte units per (py, parity) row (19 used)
-constexpr int ROWB = UNITS * 16;                       // 512 B
-constexpr int PLANE = PH * 2 * ROWB;                   // 21,504 B per plane (hi / lo)
-constexpr int STEPS = 2 * KS;                          // 14 MFMA steps (8 taps per filter row)
-constexpr int WBYTES = STEPS * 2 * 64 * 16;            // 28,672 B: [step][plane][lane] x 16 B
-constexpr int LDS_BYTES = 2 * PLANE + WBYTES;          // 71,680 B
-constexpr int THREADS = 256;
-}  // namespace cp1
-
-struct ConvPatchParams {
-    const uint8_t* x;       // packed split-fp16 input [NB][H][W][8 hi | 8 lo]
-    const uint8_t* w;       // [14][2][64][8] halves: B fragments in lane order, pre-scaled
-    const float* bias;      // [16]
-    uint8_t* y;             // split-fp16 blocked output [NB][Ho][Wo][16 hi | 16 lo]
-    const uint8_t* zeros;
-    int H, W, Ho, Wo, pad_t, pad_l;
-    int tiles_x, tiles_y, ntiles;
-    float out_scale;
-    float bias_scale;           // accumulator init = bias * bias_scale
-    unsigned* range;            // atomicMax of the stored activations' bit patterns (range monitor); may be null
-    // FUSED = true: the patch is built from the raw inputs (mask + pack fused in, the packed tensor
-    // is never materialised): davo.py:1519-1522 (u8 -> f32), :1115,1178 (LUT attention), :1404-1442
-    const uint8_t* img;     // u8 [B][H][3W][3]
-    const float* flow;      // [B][4][H][W][2]
-    const float* seg;       // [B][3][H][W][1]
-    const float* tab;       // [B][3][19] attention tables (se_excite)
-    Variant v;
-};
-
 // Persistent form: the grid is 2 workgroups per CU; each stages the 28 KB of B fragments once and
 // then walks its share of the output tiles (tile t, t + gridDim.x, ...), re-filling only the 25 KB
 // input patch per tile.  With one launch-wide weight fetch instead of one per tile the kernel's

@@ -1,0 +1,196 @@
+// ctx.h — host-side state of one davo_ctx (include/davo_hip.h) and the small helpers every
+// translation unit of libdavo_hip.so shares.  Host code only; the kernels live in conv_igemm.h,
+// conv_igemm_h3.h, conv_patch_h3.h and prologue.h and are launched through launch.h.
+//
+// Translation units (built in parallel by davo_amd/_lib.py, linked into one shared library):
+//   api.hip         extern "C" entry points (context, weights, forward, calibration, test hooks)
+//   forward.hip     the forward plan of the pose path (which kernel, which buffers, in what order)
+//   plan.hip        launch planning: tile shapes and whole-round launch splits (pure host logic)
+//   weights.hip     weight re-layout: HWIO float32 -> packed f32 / split-fp16 operands
+//   launch_f32.hip  conv_igemm_f32 instantiations + dispatch
+//   launch_h3.hip   conv_igemm_h3 instantiations + dispatch (the f16x3 path, the long compile)
+//   launch_misc.hip prologue / pose head / cnv1 patch / direct-convolution kernels + dispatch
+//   comm.hip        RCCL communicator behind the C ABI (pose gather of the window-sharded driver)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/davo_hip.h"
+#include "params.h"
+
+namespace davo {
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    float* dev = nullptr;          // raw copy in the reference layout (impl 1, pose_head, SE)
+};
+
+struct ConvLayer {
+    const char* label;
+    int KS, stride, rate;
+    int cin, cin_log2, cout;       // packed input channels per tap (power of two), valid outputs
+    int BN, npad, kpad, nchunks, groups;
+    float* d_w = nullptr;          // [groups][npad][kpad]
+    float* d_b = nullptr;          // [groups][npad]
+    // f16x3 path (conv_igemm_h3.h): channel-blocked k order, split-fp16 packed weights
+    int cb_log2 = 0, tpc_log2 = 0, cpb = 0, nchunks_h = 0, npad_h = 0, tile_h = 0;
+    float wscale = 1.f;            // power of two the packed fp16 weights are multiplied by
+    uint8_t* d_wh = nullptr;       // [groups][npad_h][nchunks_h][32 hi | 32 lo] halves
+    float* d_bh = nullptr;         // [groups][npad_h]
+};
+
+struct ProfEntry {
+    std::string name;
+    int launches = 0;
+    double total_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+// One in-flight batch: its own HIP stream and activation workspace.  Weights are shared.
+struct Slot {
+    hipStream_t stream = nullptr;
+    float *d_partial = nullptr, *d_tab = nullptr, *d_packed = nullptr, *d_pose_partial = nullptr;
+    float* d_act[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+struct Comm;                                     // comm.hip: RCCL communicator state
+
+}  // namespace davo
+
+struct davo_ctx {
+    int device = 0, H = 0, W = 0, max_batch = 0;
+    std::vector<davo::Slot> slots;             // slots[0] is created by davo_create
+    int inflight = 1, next_slot = 0;
+    bool user_stream = false;
+    bool opt_fuse_pose = true;                 // f16x3: pose head fused into cnv7's epilogue (davo_set_option)
+    bool opt_fuse_pack = false;                // f16x3: mask+pack fused into cnv1's patch fill
+    float* d_pose_tiles = nullptr;             // per-tile partial sums of the fused pose head
+    size_t pose_tiles_floats = 0;
+    bool cnv7_valid = true;
+    davo::Variant v{};
+    int impl = 0;
+    int precision = 1;                         // 0 = FP32 MFMA (bit-exact fmaf chains), 1 = f16x3 split (default)
+    bool packed_h_ready = false;
+    int last_precision = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    std::map<std::string, davo::HostTensor> weights;
+    std::vector<std::string> needed;
+    bool packed_ready = false;
+    davo::ConvLayer L[7];                      // cnv1..cnv5, cnv6 (fused), cnv7 (grouped)
+    float *d_wpred = nullptr, *d_bpred = nullptr;
+    uint8_t* d_w1patch = nullptr;              // cnv1 B fragments for conv_patch_cnv1_h3
+    // geometry
+    int H1, W1, H2, W2, H3, W3;
+    // workspace
+    float *d_partial = nullptr, *d_tab = nullptr, *d_packed = nullptr, *d_zeros = nullptr, *d_pose_partial = nullptr;
+    float* d_act[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t act_floats_per_img[7];
+    int act_ch[7];
+    int packed_ld = 8;
+    int last_B = 0;
+    bool packed_valid = true;                  // false when cnv1 consumed the raw inputs directly (fused)
+    const void *last_img = nullptr, *last_flow = nullptr, *last_seg = nullptr;
+    int last_plan[7][2] = {};                  // per layer, per launch: 128-row M tiles * 1000 + tile id / BN (reported by the bench)
+    // host-API staging
+    void *s_img = nullptr, *s_flow = nullptr, *s_seg = nullptr, *s_pose = nullptr;
+    hipStream_t copy_stream = nullptr;         // H2D of the next sub-batch runs here while the previous one computes
+    std::vector<hipEvent_t> copy_done;
+    // f16x3 range management: activations are stored as fp16 pairs scaled by 2^act_shift[layer] (davo_calibrate);
+    // every storing epilogue atomicMax-es the largest stored magnitude into d_range[layer]
+    int act_shift[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned* d_range = nullptr;               // [8]
+    bool range_dirty = false;                  // an f16x3 forward_device ran since the record was last checked
+    int host_chunk = 8;                        // davo_forward: windows per sub-batch (davo_set_option "host_chunk"; 0 = whole batch)
+    // profiling
+    bool prof = false;
+    bool prof_dominant_only = false;           // profile mode 2: bracket only the main cnv6 launch
+    std::vector<davo::ProfEntry> prof_entries;
+    std::vector<hipEvent_t> event_pool;
+    // multi-GPU (comm.hip)
+    davo::Comm* comm = nullptr;
+};
+
+namespace davo {
+
+inline int fail(davo_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return ::davo::fail(c, DAVO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                __FILE__, __LINE__);                                           \
+    } while (0)
+
+// TF `SAME` padding (SURVEY.md note P): out = ceil(in/stride), pad_before = total // 2
+inline void same_pad(int in, int k, int stride, int rate, int* out, int* before) {
+    const int o = (in + stride - 1) / stride;
+    const int keff = (k - 1) * rate + 1;
+    int total = (o - 1) * stride + keff - in;
+    if (total < 0) total = 0;
+    *out = o;
+    *before = total / 2;
+}
+
+inline int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+// ---- profiling: HIP events around a launch on the launch stream -----------------------------
+struct ProfScope {
+    davo_ctx* c;
+    ProfEntry* e = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(davo_ctx* ctx, const char* name);
+    ~ProfScope();
+};
+int prof_collect(davo_ctx* c);
+int sync_all_slots(davo_ctx* c);
+
+// ---- weights.hip ----------------------------------------------------------------------------
+void init_layer(ConvLayer& L, const char* label, int KS, int stride, int rate, int cin, int cout, int groups);
+std::vector<std::string> needed_names(const Variant& v);
+bool expected_shape(const davo_ctx* c, const std::string& name, std::vector<int64_t>* sh);
+int upload(davo_ctx* c, const std::vector<float>& host, float** dev);
+int build_packed_weights(davo_ctx* c);
+int build_packed_weights_h3(davo_ctx* c);
+int missing_weights(davo_ctx* c, std::string* names);
+float weight_prescale(const float* w, size_t n);
+void pack_conv_weights(const float* w_tf, int KS, int cin_tf, int cout, const int* chmap, int cin_packed,
+                       int npad, int kpad, float* out);
+void pack_conv_weights_h3(const float* w_tf, int KS, int cin_tf, int cout, const int* chmap, int cin_packed,
+                          int cb_log2, int tpc_log2, int cpb, int nchunks, float scale, _Float16* out);
+inline void split_f16(float v, _Float16* hi, _Float16* lo) {
+    const _Float16 h = (_Float16)v;
+    *hi = h;
+    *lo = (_Float16)(v - (float)h);
+}
+
+// ---- forward.hip ----------------------------------------------------------------------------
+void activate_slot(davo_ctx* c, int i);
+int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, void* d_pose);
+// f16x3: verdict on the range record (d_range) read back from the device; DAVO_ERR_RANGE names the layer
+int check_range(davo_ctx* c, const unsigned raw[6]);
+
+// ---- comm.hip -------------------------------------------------------------------------------
+void comm_release(davo_ctx* c);
+
+}  // namespace davo

@@ -1,0 +1,347 @@
+// forward.hip — the forward plan of the pose path on one context:
+//
+//   se_squeeze_partial -> se_excite -> mask_pack -> cnv1..cnv5 -> cnv6 (rotation|translation
+//   fused into one N = 2*cnv6_out GEMM, both read cnv5: nets/posenn.py:222-238)
+//   -> cnv7 (grouped x2) -> pose head.
+//
+// The two PoseNN calls of a triplet (davo.py:1456-1457, shared weights) run as one batch of
+// 2B pair images.  Host code only: kernels are reached through launch.h.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "ctx.h"
+#include "launch.h"
+#include "plan.h"
+
+namespace davo {
+
+// ---- profiling ------------------------------------------------------------------------------------
+ProfScope::ProfScope(davo_ctx* ctx, const char* name) : c(ctx) {
+    if (!c->prof) return;
+    if (c->prof_dominant_only && strcmp(name, "cnv6") != 0) return;
+    for (auto& pe : c->prof_entries)
+        if (pe.name == name) { e = &pe; break; }
+    if (!e) {
+        c->prof_entries.emplace_back();
+        e = &c->prof_entries.back();
+        e->name = name;
+    }
+    auto get = [&]() {
+        hipEvent_t ev = nullptr;
+        if (!c->event_pool.empty()) { ev = c->event_pool.back(); c->event_pool.pop_back(); }
+        else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+        return ev;
+    };
+    a = get(); b = get();
+    if (a) (void)hipEventRecord(a, c->stream);
+}
+
+ProfScope::~ProfScope() {
+    if (!e) return;
+    if (b) (void)hipEventRecord(b, c->stream);
+    if (a && b) e->pending.emplace_back(a, b);
+    else {                                    // half a pair is of no use: back to the pool
+        if (a) c->event_pool.push_back(a);
+        if (b) c->event_pool.push_back(b);
+    }
+}
+
+int sync_all_slots(davo_ctx* c) {
+    for (auto& s : c->slots) HIP_TRY(c, hipStreamSynchronize(s.stream));
+    if (c->user_stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DAVO_OK;
+}
+
+int prof_collect(davo_ctx* c) {
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    for (auto& pe : c->prof_entries) {
+        for (auto& ab : pe.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ab.first, ab.second) == hipSuccess) {
+                pe.total_ms += ms;
+                pe.launches += 1;
+            }
+            c->event_pool.push_back(ab.first);
+            c->event_pool.push_back(ab.second);
+        }
+        pe.pending.clear();
+    }
+    return DAVO_OK;
+}
+
+// bind a slot's stream and workspace to the members every launch helper uses
+void activate_slot(davo_ctx* c, int i) {
+    const Slot& s = c->slots[i];
+    if (!(c->user_stream && i == 0)) c->stream = s.stream;
+    c->d_partial = s.d_partial; c->d_tab = s.d_tab; c->d_packed = s.d_packed; c->d_pose_partial = s.d_pose_partial;
+    for (int k = 0; k < 7; ++k) c->d_act[k] = s.d_act[k];
+}
+
+// f16x3 only.  Stored activations (fp16 hi/lo pairs) are float32-grade while the layer's largest stored value is
+// below the fp16 maximum (above it values were clamped) and not so small that the pairs lose their low bits
+// (tools/exp_activation_scale.py: the 1e-4 bar holds down to ~2^-16 of O(1) activations; 2^-11 is the guard).
+int check_range(davo_ctx* c, const unsigned raw[6]) {
+    static const char* names[6] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6"};
+    for (int i = 0; i < 6; ++i) {
+        float v;
+        memcpy(&v, &raw[i], sizeof v);
+        const float actual = ldexpf(v, -c->act_shift[i]);
+        if (!(v < 65504.f))
+            return fail(c, DAVO_ERR_RANGE, "%s activations reach %.4g: outside the fp16-pair storage range at scale 2^%d "
+                        "(values were clamped) - run davo_calibrate() or davo_set_precision(ctx, 0)", names[i], (double)actual, c->act_shift[i]);
+        if (v > 0.f && v < 0x1p-11f)
+            return fail(c, DAVO_ERR_RANGE, "%s activations are at most %.4g: too small for the fp16-pair storage at scale 2^%d "
+                        "- run davo_calibrate() or davo_set_precision(ctx, 0)", names[i], (double)actual, c->act_shift[i]);
+    }
+    return DAVO_OK;
+}
+
+namespace {
+
+// ---- one conv layer, FP32-MFMA path ---------------------------------------------------------------
+int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int Win, float* y, int y_ld, int NB) {
+    const ConvLayer& L = c->L[li];
+    ConvParams p{};
+    int Ho, Wo, pt, pl;
+    same_pad(Hin, L.KS, L.stride, L.rate, &Ho, &pt);
+    same_pad(Win, L.KS, L.stride, L.rate, &Wo, &pl);
+    p.x = x; p.w = L.d_w; p.bias = L.d_b; p.y = y; p.zeros = c->d_zeros;
+    p.Hin = Hin; p.Win = Win; p.Hout = Ho; p.Wout = Wo;
+    p.cin_log2 = L.cin_log2; p.x_ld = x_ld; p.x_coff = 0; p.y_ld = y_ld; p.y_coff = 0;
+    p.Cout = L.cout; p.pad_t = pt; p.pad_l = pl; p.rate = L.rate;
+    p.M = NB * Ho * Wo; p.nchunks = L.nchunks; p.Kpad = L.kpad; p.ntaps = L.KS * L.KS;
+    p.ntiles_n = L.npad / L.BN; p.relu = 1;
+    if (L.groups == 2) {
+        p.g_x_coff = L.cin; p.g_y_coff = L.cout;
+        p.g_w = (long)L.npad * L.kpad; p.g_bias = L.npad;
+    }
+    const int mtiles = (p.M + BM - 1) / BM;
+    const std::vector<Launch> plan = plan_layer(mtiles, L.npad, L.groups);
+    c->last_plan[li][0] = c->last_plan[li][1] = 0;
+    for (size_t i = 0; i < plan.size(); ++i) {
+        p.mtile0 = plan[i].mtile0;
+        p.ntiles_n = L.npad / plan[i].BN;
+        dim3 grid(plan[i].mtiles * p.ntiles_n, L.groups);
+        const std::string label = i == 0 ? std::string(L.label) : std::string(L.label) + ".rem";
+        ProfScope ps(c, label.c_str());
+        HIP_TRY(c, launch_layer(li, plan[i].BN, p, grid, c->stream));
+        c->last_plan[li][i] = plan[i].mtiles * 1000 + plan[i].BN;
+    }
+    return DAVO_OK;
+}
+
+// ---- one conv layer, f16x3 path: x and y are split-fp16 blocked tensors (y float32 when y_f32) -----
+int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int Win, void* y, int y_ld,
+                      bool y_f32, int NB, bool fuse_pose = false, int* pose_bm = nullptr, int* pose_mt = nullptr,
+                      int* pose_ntn = nullptr) {
+    const ConvLayer& L = c->L[li];
+    ConvParamsH p{};
+    int Ho, Wo, pt, pl;
+    same_pad(Hin, L.KS, L.stride, L.rate, &Ho, &pt);
+    same_pad(Win, L.KS, L.stride, L.rate, &Wo, &pl);
+    p.x = static_cast<const uint8_t*>(x); p.w = L.d_wh; p.bias = L.d_bh; p.y = static_cast<uint8_t*>(y);
+    p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
+    p.Hin = Hin; p.Win = Win; p.Hout = Ho; p.Wout = Wo;
+    p.x_pix_bytes = (long)x_ch * 4; p.x_boff = 0;
+    p.cb_log2 = L.cb_log2; p.tpc_log2 = L.tpc_log2; p.cpb = L.cpb; p.nchunks = L.nchunks_h;
+    p.w_row_bytes = (long)L.nchunks_h * 128;
+    p.y_mode = y_f32 ? 0 : 1; p.y_ld = y_ld; p.y_coff = 0; p.Cout = L.cout;
+    p.pad_t = pt; p.pad_l = pl; p.rate = L.rate;
+    p.M = NB * Ho * Wo; p.ntaps = L.KS * L.KS; p.mtile0 = 0; p.relu = 1;
+    {   // stored activations carry 2^act_shift (exact); cnv7 feeds the float32 pose head unscaled
+        const int sin = li == 0 ? 0 : c->act_shift[li - 1], sout = li == 6 ? 0 : c->act_shift[li];
+        p.out_scale = ldexpf(1.0f / L.wscale, sout - sin);
+        p.bias_scale = ldexpf(L.wscale, sin);
+        p.range = c->d_range ? c->d_range + li : nullptr;
+    }
+    if (L.groups == 2) {
+        p.g_x_boff = L.cin * 4; p.g_y_coff = L.cout;
+        p.g_w = (long)L.npad_h * p.w_row_bytes; p.g_bias = L.npad_h;
+    }
+    if (const char* e = tuning_env("DAVO_DBG")) p.dbg = atoi(e);       // tuning build only
+    std::vector<LaunchH> plan = plan_layer_h3(p.M, L.npad_h, L.groups, L.tile_h);
+    if (fuse_pose) {      // one launch, one tile shape no taller than an image, so a tile touches <= 2 images
+        const int P = Ho * Wo;
+        const int best = plan_single_tile_h3(p.M, L.npad_h, L.groups, P, L.tile_h);
+        if (best < 0) return fail(c, DAVO_ERR_INVALID, "no tile fits the fused pose head");
+        plan = {{0, p.M, best}};
+        const TileShape ts = tile_shape(best);
+        const int mt = (p.M + ts.bm - 1) / ts.bm, ntn = L.npad_h / ts.bn;
+        const size_t need = (size_t)L.groups * mt * ntn * 6;
+        if (need > c->pose_tiles_floats) {
+            if (c->d_pose_tiles) { int rs = sync_all_slots(c); if (rs) return rs; HIP_TRY(c, hipFree(c->d_pose_tiles)); c->d_pose_tiles = nullptr; }
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_pose_tiles), need * sizeof(float) * 4));   // x4: one region per in-flight slot
+            c->pose_tiles_floats = need;
+        }
+        const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;      // the slot this batch runs in
+        p.y_mode = 2; p.pose_w = c->d_wpred; p.pose_partial = c->d_pose_tiles + (size_t)slot_idx * c->pose_tiles_floats;
+        p.pose_P = P; p.pose_mt = mt;
+        if (pose_bm) *pose_bm = ts.bm;
+        if (pose_mt) *pose_mt = mt;
+        if (pose_ntn) *pose_ntn = ntn;
+    }
+    c->last_plan[li][0] = c->last_plan[li][1] = 0;
+    for (size_t i = 0; i < plan.size() && i < 2; ++i) {
+        const TileShape ts = tile_shape(plan[i].tile);
+        p.ntiles_n = L.npad_h / ts.bn;
+        p.mtile0 = plan[i].row0 / ts.bm;
+        const int full_m = p.M;
+        p.M = plan[i].row0 + plan[i].rows;                    // rows past this launch's range are not its job
+        const int mtiles = (plan[i].rows + ts.bm - 1) / ts.bm;
+        dim3 grid(mtiles * p.ntiles_n, L.groups);
+        c->last_plan[li][i] = ((plan[i].rows + 127) / 128) * 1000 + plan[i].tile;
+        const std::string label = i == 0 ? std::string(L.label) : std::string(L.label) + ".rem";
+        {
+            ProfScope ps(c, label.c_str());
+            HIP_TRY(c, launch_layer_h3(li, plan[i].tile, p, grid, c->stream));
+        }
+        p.M = full_m;
+    }
+    return DAVO_OK;
+}
+
+// cnv1 of the f16x3 path from an LDS-staged input patch (conv_patch_h3.h).  fused: the patch is built
+// from the raw inputs (mask + pack fused in); otherwise it is copied from the packed tensor.
+int run_cnv1_patch(davo_ctx* c, bool fused, const void* d_img, const void* d_flow, const void* d_seg, void* y, int NB) {
+    const ConvLayer& L = c->L[0];
+    ConvPatchParams p{};
+    int Ho, Wo, pt, pl;
+    same_pad(c->H, 7, 2, 1, &Ho, &pt);
+    same_pad(c->W, 7, 2, 1, &Wo, &pl);
+    p.x = reinterpret_cast<const uint8_t*>(c->d_packed); p.w = c->d_w1patch; p.bias = L.d_bh; p.y = static_cast<uint8_t*>(y);
+    p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
+    p.H = c->H; p.W = c->W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pt; p.pad_l = pl;
+    p.tiles_x = (Wo + cp1::TW - 1) / cp1::TW; p.tiles_y = (Ho + cp1::TH - 1) / cp1::TH;
+    p.out_scale = ldexpf(1.0f / L.wscale, c->act_shift[0]);
+    p.bias_scale = L.wscale;
+    p.range = c->d_range;
+    p.ntiles = NB * p.tiles_x * p.tiles_y;
+    p.img = static_cast<const uint8_t*>(d_img); p.flow = static_cast<const float*>(d_flow);
+    p.seg = static_cast<const float*>(d_seg); p.tab = c->d_tab; p.v = c->v;
+    c->last_plan[0][0] = ((NB * Ho * Wo + 127) / 128) * 1000 + 99; c->last_plan[0][1] = 0;
+    const int nblk = p.ntiles < 512 ? p.ntiles : 512;          // 2 workgroups per CU, each walks its tiles
+    ProfScope ps(c, "cnv1");
+    HIP_TRY(c, launch_cnv1_patch(fused, p, nblk, c->stream));
+    return DAVO_OK;
+}
+
+int run_direct(davo_ctx* c, const char* label, const float* x, int N, int Hin, int Win, int cin, int x_ld,
+               int x_coff, const std::string& wname, const std::string& bname, int KS, int cout, int stride,
+               int rate, float* y, int y_ld, int y_coff) {
+    int Ho, Wo, pt, pl;
+    same_pad(Hin, KS, stride, rate, &Ho, &pt);
+    same_pad(Win, KS, stride, rate, &Wo, &pl);
+    ProfScope ps(c, label);
+    HIP_TRY(c, launch_conv_direct(x, N, Hin, Win, cin, x_ld, x_coff, c->weights.at(wname).dev, KS, cout,
+                                  c->weights.at(bname).dev, stride, rate, pt, pl, Ho, Wo, 1, y, y_ld, y_coff, c->stream));
+    return DAVO_OK;
+}
+
+}  // namespace
+
+int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, void* d_pose) {
+    if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
+    if (!d_img || !d_flow || !d_seg || !d_pose) return fail(c, DAVO_ERR_INVALID, "null device pointer");
+    {
+        std::string names;
+        if (missing_weights(c, &names)) return fail(c, DAVO_ERR_NOT_READY, "weights not loaded: %s", names.c_str());
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->packed_ready) { int rc = build_packed_weights(c); if (rc) return rc; }
+    const bool h3 = c->impl == 0 && c->precision == 1;
+    if (h3 && !c->packed_h_ready) { int rc = build_packed_weights_h3(c); if (rc) return rc; }
+
+    const int H = c->H, W = c->W, HW = H * W, NB = 2 * B;
+    const Variant& v = c->v;
+    hipStream_t s = c->stream;
+    auto wdev = [&](const char* n) -> const float* {
+        auto it = c->weights.find(n);
+        return it == c->weights.end() ? nullptr : it->second.dev;
+    };
+    if (v.att_source == 1) {
+        ProfScope ps(c, "se_squeeze_partial");
+        HIP_TRY(c, launch_se_squeeze(static_cast<const float*>(d_flow), B, HW, v, c->d_partial, s));
+    }
+    {
+        ProfScope ps(c, "se_excite");
+        HIP_TRY(c, launch_se_excite(c->d_partial, B, HW, v,
+                                    wdev("pose_exp_net/se_flow/bottleneck_fc/kernel"), wdev("pose_exp_net/se_flow/bottleneck_fc/bias"),
+                                    wdev("pose_exp_net/se_flow/recover_fc/kernel"), wdev("pose_exp_net/se_flow/recover_fc/bias"),
+                                    wdev("pose_exp_net/pose_exp_net/seg_channel_weight/weight"), c->d_tab, s));
+    }
+    // f16x3, fuse_pack: cnv1 builds its input patch straight from the raw inputs (mask + pack fused in,
+    // the packed tensor never touches HBM).  Measured equal in time to mask_pack + cnv1 (the fused fill is bound
+    // by its byte loads), so the two-kernel form stays the default.  Tuning build: DAVO_FUSE_PACK=1 / DAVO_CNV1_PATCH=0.
+    const char* fe = tuning_env("DAVO_FUSE_PACK");
+    const char* pe = tuning_env("DAVO_CNV1_PATCH");
+    const bool fuse_env = (fe && atoi(fe) == 1) || c->opt_fuse_pack;
+    const bool patch1 = !(pe && atoi(pe) == 0);
+    const bool fused = h3 && patch1 && fuse_env;
+    c->packed_valid = !fused;
+    c->last_img = d_img; c->last_flow = d_flow; c->last_seg = d_seg;
+    c->packed_ld = c->impl == 0 ? 8 : 10;
+    if (!fused) {
+        ProfScope ps(c, "mask_pack");
+        HIP_TRY(c, launch_mask_pack(h3 ? 16 : (c->impl == 0 ? 8 : 10), static_cast<const uint8_t*>(d_img),
+                                    static_cast<const float*>(d_flow), static_cast<const float*>(d_seg), c->d_tab, v, B, H, W,
+                                    c->d_packed, s));
+    }
+    const int c6 = v.cnv6_out;
+    float** a = c->d_act;
+    int rc;
+    bool pose_fused = false;
+    int pose_bm = 0, pose_mt = 0, pose_ntn = 0;
+    c->cnv7_valid = true;
+    if (h3) {
+        if (patch1) { if ((rc = run_cnv1_patch(c, fused, d_img, d_flow, d_seg, a[0], NB))) return rc; }
+        else if ((rc = run_conv_layer_h3(c, 0, c->d_packed, 8, H, W, a[0], 16, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 3, a[2], 64, c->H2, c->W2, a[3], 128, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 4, a[3], 128, c->H2, c->W2, a[4], 256, false, NB))) return rc;
+        if ((rc = run_conv_layer_h3(c, 5, a[4], 256, c->H2, c->W2, a[5], 2 * c6, false, NB))) return rc;
+        pose_fused = c->opt_fuse_pose && c->H3 * c->W3 >= 128;
+        if ((rc = run_conv_layer_h3(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, true, NB, pose_fused, &pose_bm, &pose_mt, &pose_ntn))) return rc;
+        c->cnv7_valid = !pose_fused;
+        c->range_dirty = true;
+    } else if (c->impl == 0) {
+        if ((rc = run_conv_layer(c, 0, c->d_packed, 8, H, W, a[0], 16, NB))) return rc;
+        if ((rc = run_conv_layer(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, NB))) return rc;
+        if ((rc = run_conv_layer(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, NB))) return rc;
+        if ((rc = run_conv_layer(c, 3, a[2], 64, c->H2, c->W2, a[3], 128, NB))) return rc;
+        if ((rc = run_conv_layer(c, 4, a[3], 128, c->H2, c->W2, a[4], 256, NB))) return rc;
+        if ((rc = run_conv_layer(c, 5, a[4], 256, c->H2, c->W2, a[5], 2 * c6, NB))) return rc;
+        if ((rc = run_conv_layer(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, NB))) return rc;
+    } else {
+        const std::string P = "pose_exp_net/";
+        const int c10 = 2 * v.cin_per_frame;
+        if (v.cin_per_frame != 5) return fail(c, DAVO_ERR_INVALID, "impl 1 supports the 10-channel (v1) input only");
+        if ((rc = run_direct(c, "cnv1", c->d_packed, NB, H, W, c10, 10, 0, P + "cnv1/weights", P + "cnv1/biases", 7, 16, 2, 1, a[0], 16, 0))) return rc;
+        if ((rc = run_direct(c, "cnv2", a[0], NB, c->H1, c->W1, 16, 16, 0, P + "cnv2/weights", P + "cnv2/biases", 5, 32, 2, 1, a[1], 32, 0))) return rc;
+        if ((rc = run_direct(c, "cnv3", a[1], NB, c->H2, c->W2, 32, 32, 0, P + "cnv3/weights", P + "cnv3/biases", 3, 64, 1, 2, a[2], 64, 0))) return rc;
+        if ((rc = run_direct(c, "cnv4", a[2], NB, c->H2, c->W2, 64, 64, 0, P + "cnv4/weights", P + "cnv4/biases", 3, 128, 1, 4, a[3], 128, 0))) return rc;
+        if ((rc = run_direct(c, "cnv5", a[3], NB, c->H2, c->W2, 128, 128, 0, P + "cnv5/weights", P + "cnv5/biases", 3, 256, 1, 8, a[4], 256, 0))) return rc;
+        const char* heads[2] = {"rotation", "translation"};
+        for (int h = 0; h < 2; ++h) {
+            const std::string hp = P + "pose/" + heads[h] + "/";
+            if ((rc = run_direct(c, "cnv6", a[4], NB, c->H2, c->W2, 256, 256, 0, hp + "cnv6/weights", hp + "cnv6/biases", 3, c6, 1, 2, a[5], 2 * c6, h * c6))) return rc;
+            if ((rc = run_direct(c, "cnv7", a[5], NB, c->H2, c->W2, c6, 2 * c6, h * c6, hp + "cnv7/weights", hp + "cnv7/biases", 3, 256, 2, 1, a[6], 512, h * 256))) return rc;
+        }
+    }
+    {
+        ProfScope ps(c, "pose_head");
+        if (pose_fused) {
+            const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;
+            HIP_TRY(c, launch_pose_from_tiles(c->d_pose_tiles + (size_t)slot_idx * c->pose_tiles_floats, NB, c->H3 * c->W3, pose_bm,
+                                              pose_mt, pose_ntn, c->d_bpred, static_cast<float*>(d_pose), s));
+        } else {
+            HIP_TRY(c, launch_pose_head(a[6], NB, c->H3 * c->W3, c->d_wpred, c->d_bpred, c->d_pose_partial, static_cast<float*>(d_pose), s));
+        }
+    }
+    c->last_B = B;
+    c->last_precision = h3 ? 1 : 0;
+    return DAVO_OK;
+}
+
+}  // namespace davo

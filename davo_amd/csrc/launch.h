@@ -1,0 +1,43 @@
+// launch.h — the kernel launch functions, one translation unit per kernel family so the device
+// code compiles in parallel.  Each launcher sets the dynamic-LDS attribute of its kernel once per
+// (device, kernel) and returns the launch's error.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "params.h"
+#include "plan.h"
+
+namespace davo {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize for `kernel` on the CURRENT device, set once per (device, kernel):
+// a function attribute belongs to the device's code object, so a second context on another GPU of the same
+// process needs its own call (launch_misc.hip).
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
+
+// ---- launch_f32.hip: conv_igemm_f32 (FP32 MFMA, bit-exact fmaf chains) ---------------------------
+// generic shapes (davo_conv2d_same and non-default cnv6 widths)
+hipError_t launch_conv(int KS, int stride, int BN, const ConvParams& p, dim3 grid, hipStream_t s);
+// the seven PoseNN layers (layer 0..6 = cnv1..cnv7), each under its own kernel name; BN is chosen per launch
+hipError_t launch_layer(int layer, int BN, const ConvParams& p, dim3 grid, hipStream_t s);
+
+// ---- launch_h3.hip: conv_igemm_h3 (f16x3) -----------------------------------------------------------
+hipError_t launch_layer_h3(int layer, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s);
+hipError_t launch_h3_generic(int KS, int stride, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s);
+
+// ---- launch_misc.hip: prologue, pose head, cnv1 patch kernel, direct convolution ---------------------
+hipError_t launch_se_squeeze(const float* d_flow, int B, int HW, const Variant& v, float* d_partial, hipStream_t s);
+hipError_t launch_se_excite(const float* d_partial, int B, int HW, const Variant& v, const float* w1, const float* b1,
+                            const float* w2, const float* b2, const float* wstatic, float* d_tab, hipStream_t s);
+// ld: 16 = split-fp16 8-channel layout (f16x3), 8 = float32 8-channel, 10 = the reference's 10-channel layout
+hipError_t launch_mask_pack(int ld, const uint8_t* d_img, const float* d_flow, const float* d_seg, const float* d_tab,
+                            const Variant& v, int B, int H, int W, float* d_packed, hipStream_t s);
+hipError_t launch_cnv1_patch(bool fused, const ConvPatchParams& p, int nblk, hipStream_t s);
+hipError_t launch_pose_from_tiles(const float* d_tiles, int NB, int P, int bm, int mtiles, int ntiles_n,
+                                  const float* d_bpred, float* d_pose, hipStream_t s);
+hipError_t launch_pose_head(const float* d_c7, int NB, int P, const float* d_wpred, const float* d_bpred,
+                            float* d_partial, float* d_pose, hipStream_t s);
+hipError_t launch_conv_direct(const float* x, int N, int Hin, int Win, int cin, int x_ld, int x_coff, const float* w, int KS,
+                              int cout, const float* bias, int stride, int rate, int pt, int pl, int Ho, int Wo, int relu,
+                              float* y, int y_ld, int y_coff, hipStream_t s);
+
+}  // namespace davo

@@ -1,0 +1,61 @@
+// launch_f32.hip — instantiations and dispatch of conv_igemm_f32 (conv_igemm.h).
+#include "conv_igemm.h"
+#include "launch.h"
+
+namespace davo {
+namespace {
+
+template <int KS, int STRIDE, int BN, int LAYER>
+hipError_t launch_conv_t(const ConvParams& p, dim3 grid, hipStream_t s) {
+    auto kern = conv_igemm_f32<KS, STRIDE, BN, LAYER>;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), Tile<BN>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(256), Tile<BN>::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+template <int KS, int STRIDE, int LAYER>
+hipError_t launch_bn(int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
+    switch (BN) {
+        case 32: return launch_conv_t<KS, STRIDE, 32, LAYER>(p, grid, s);
+        case 64: return launch_conv_t<KS, STRIDE, 64, LAYER>(p, grid, s);
+        case 128: return launch_conv_t<KS, STRIDE, 128, LAYER>(p, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+hipError_t launch_conv(int KS, int stride, int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
+    if (stride == 1) {
+        switch (KS) {
+            case 1: return launch_bn<1, 1, 0>(BN, p, grid, s);
+            case 3: return launch_bn<3, 1, 0>(BN, p, grid, s);
+            case 5: return launch_bn<5, 1, 0>(BN, p, grid, s);
+            case 7: return launch_bn<7, 1, 0>(BN, p, grid, s);
+        }
+    } else if (stride == 2) {
+        switch (KS) {
+            case 1: return launch_bn<1, 2, 0>(BN, p, grid, s);
+            case 3: return launch_bn<3, 2, 0>(BN, p, grid, s);
+            case 5: return launch_bn<5, 2, 0>(BN, p, grid, s);
+            case 7: return launch_bn<7, 2, 0>(BN, p, grid, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_layer(int layer, int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
+    switch (layer) {
+        case 0: return launch_bn<7, 2, 1>(BN, p, grid, s);
+        case 1: return launch_bn<5, 2, 2>(BN, p, grid, s);
+        case 2: return launch_bn<3, 1, 3>(BN, p, grid, s);
+        case 3: return launch_bn<3, 1, 4>(BN, p, grid, s);
+        case 4: return launch_bn<3, 1, 5>(BN, p, grid, s);
+        case 5: return launch_bn<3, 1, 6>(BN, p, grid, s);
+        case 6: return launch_bn<3, 2, 7>(BN, p, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace davo

@@ -1,0 +1,76 @@
+// launch_h3_impl.h — templates shared by the two translation units that instantiate conv_igemm_h3
+// (launch_h3.hip: the seven PoseNN layers; launch_h3_generic.hip: davo_conv2d_same's generic shapes).
+#pragma once
+#include <cstdlib>
+
+#include "conv_igemm_h3.h"
+#include "launch.h"
+
+namespace davo {
+namespace h3impl {
+
+#ifndef DAVO_REM_STAGES
+#define DAVO_REM_STAGES 3
+#endif
+
+// v_mfma 16x16x32 instead of 32x32x16 for the large tiles (higher held clock under matrix-dense load);
+// tuning build only: DAVO_H3_M16=0 selects the 32x32x16 form (A/B measurements)
+inline bool use_m16() {
+    static int v = -1;
+    if (v < 0) { const char* e = tuning_env("DAVO_H3_M16"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
+// All f16x3 launches are LDS-DMA staged.  SMALLC (Cin < 32) is a property of the layer.
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool SMALLC, bool M16, int NSTG = 2>
+hipError_t launch_m(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    using T = TileH<WM, WN, TM, TN, NSTG>;
+    auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, true, SMALLC, M16, NSTG>;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES_DMA);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(T::THREADS), T::LDS_BYTES_DMA, s, p);
+    return hipGetLastError();
+}
+
+// The 16x16x32 form is used for EVERY tile shape of cnv3..cnv7, so that an output element is summed in the
+// same order whatever tile the launch plan gives it (batch-size invariance to the bit).
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool SMALLC>
+hipError_t launch_c(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    if constexpr (LAYER >= 3 && !SMALLC) {
+        if (use_m16()) return launch_m<KS, STRIDE, WM, WN, TM, TN, LAYER, SMALLC, true>(p, grid, s);
+    }
+    return launch_m<KS, STRIDE, WM, WN, TM, TN, LAYER, SMALLC, false>(p, grid, s);
+}
+
+// MAXBN bounds the instantiations to the N tiles a layer can use (its padded Cout)
+template <int KS, int STRIDE, int LAYER, bool SMALLC, int MAXBN>
+hipError_t launch_tile(int tile, const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    if (tile == TILE_128x32) return launch_c<KS, STRIDE, 4, 1, 1, 1, LAYER, SMALLC>(p, grid, s);
+    if constexpr (MAXBN >= 64)
+        if (tile == TILE_256x64) return launch_c<KS, STRIDE, 4, 2, 2, 1, LAYER, SMALLC>(p, grid, s);
+    if constexpr (MAXBN >= 128) {
+        if (tile == TILE_256x128) return launch_c<KS, STRIDE, 4, 2, 2, 2, LAYER, SMALLC>(p, grid, s);
+        if (tile == TILE_128x128) {
+            // cnv7 (stride 2, pose head in the epilogue): four waves of 64x64 measured 7 % faster than eight of
+            // 32x64 (fewer LDS fragment reads per MFMA); the stride-1 layers measured the other way round
+            if constexpr (LAYER == 7) return launch_c<KS, STRIDE, 2, 2, 2, 2, LAYER, SMALLC>(p, grid, s);
+            else {
+                // a launch of at most one workgroup per CU (remainder rows) has no second workgroup to hide the
+                // DMA latency behind: three ring slots instead of two (cnv6.rem 0.073 -> 0.061 ms, cnv5.rem 0.041 -> 0.036)
+                if constexpr (LAYER >= 3 && !SMALLC)
+                    if ((long)grid.x * grid.y <= 256 && use_m16())
+                        return launch_m<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC, true, DAVO_REM_STAGES>(p, grid, s);
+                return launch_c<KS, STRIDE, 4, 2, 1, 2, LAYER, SMALLC>(p, grid, s);
+            }
+        }
+    }
+    if constexpr (MAXBN >= 256) {
+        if (tile == TILE_128x256) return launch_c<KS, STRIDE, 2, 4, 2, 2, LAYER, SMALLC>(p, grid, s);
+        if constexpr (LAYER != 0)
+            if (tile == TILE_256x256) return launch_c<KS, STRIDE, 4, 2, 2, 4, LAYER, SMALLC>(p, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace h3impl
+}  // namespace davo

@@ -1,0 +1,138 @@
+// params.h — kernel parameter blocks, tile geometry and constants shared by the kernels
+// (conv_igemm.h, conv_igemm_h3.h, conv_patch_h3.h, prologue.h) and the host code that plans and
+// launches them.  No device code here, so host-only translation units include it cheaply.
+#pragma once
+#include <stdint.h>
+
+namespace davo {
+
+constexpr int NCLS = 19;            // Cityscapes train ids (utils/seg_utils/labels.py:64-101)
+constexpr int SQ_CHUNKS = 32;       // SE squeeze: partial sums per (triplet, source) plane
+constexpr int PH_SPLIT = 8;         // pose head: partial sums per (image, head)
+
+struct Variant {
+    int cin_per_frame, cnv6_out, se_act, norm_flow, abs_mode, att_source, mask_rgb, mask_info;
+};
+
+// ---- conv_igemm.h (FP32 MFMA) ------------------------------------------------------------
+struct ConvParams {
+    const float* x;       // input activation, pixel-major NHWC
+    const float* w;       // packed weights [Npad][Kpad]
+    const float* bias;    // [Npad]
+    float* y;             // output activation
+    const float* zeros;   // >= 16 bytes of zeros: what a padded (out-of-image) tap reads
+    int Hin, Win, Hout, Wout;
+    int cin_log2;         // Cin = 1 << cin_log2 (channels per tap in the packed k order)
+    int x_ld, x_coff;     // floats per input pixel, first channel used
+    int y_ld, y_coff;     // floats per output pixel, first channel written
+    int Cout;             // valid output channels (per group)
+    int pad_t, pad_l, rate;
+    int M;                // images * Hout * Wout
+    int nchunks, Kpad, ntaps;
+    int ntiles_n;
+    int mtile0;           // first 128-row M tile of this launch (a layer may be split in two launches)
+    int relu;
+    // grouped launch (blockIdx.y = group): per-group strides
+    int g_x_coff, g_y_coff;
+    long g_w, g_bias;
+};
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDK = 36;          // padded LDS row (floats)
+
+template <int BN> struct Tile {
+    static constexpr int WN = BN >= 64 ? 2 : 1;    // waves along N
+    static constexpr int WM = 4 / WN;              // waves along M
+    static constexpr int TM = BM / WM / 32;        // 32x32 MFMA tiles per wave along M
+    static constexpr int TN = BN / WN / 32;
+    static constexpr int NB_LOADS = BN / 32;       // float4 weight loads per thread per chunk
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDK * 4;
+};
+
+// ---- conv_igemm_h3.h (f16x3) --------------------------------------------------------------
+struct ConvParamsH {
+    const uint8_t* x;       // split-fp16 blocked activation
+    const uint8_t* w;       // packed weights: [Npad][nchunks][32 hi | 32 lo] halves (128 B per chunk)
+    const float* bias;      // [Npad]
+    uint8_t* y;             // output: float32 NHWC (y_mode 0) or split-fp16 blocked (y_mode 1)
+    const uint8_t* zeros;   // >= 16 zero bytes: what a padded (out-of-image) tap reads
+    int Hin, Win, Hout, Wout;
+    long x_pix_bytes;       // bytes per input pixel (all channels of the tensor x 4)
+    int x_boff;             // byte offset inside a pixel of the first channel block used
+    int cb_log2;            // CB = channels per block = min(Cin, 32)
+    int tpc_log2;           // taps per chunk = 32 / CB
+    int cpb;                // chunks per channel block = ceil(ntaps / taps per chunk)
+    int nchunks;
+    long w_row_bytes;       // nchunks * 128
+    int y_mode, y_ld, y_coff, Cout;
+    int pad_t, pad_l, rate;
+    int M, ntaps, ntiles_n, mtile0, relu;
+    int g_x_boff, g_y_coff;
+    long g_w, g_bias;
+    float out_scale;        // 2^(shift_out - shift_in) / (power of two the layer's weights were multiplied by)
+    float bias_scale;       // accumulator init = bias * bias_scale (weight scale * 2^shift_in; a power of two)
+    unsigned* range;        // y_mode 1: atomicMax of the stored (scaled) activations' bit patterns; may be null
+    // y_mode 2 (cnv7 only): the pose head is fused into the epilogue, nothing is stored but this tile's
+    // contribution to sum_pixels sum_channels relu(cnv7) * Wpred[c][k] for the (at most two) images it touches
+    const float* pose_w;    // [groups][256][3] pred kernels
+    float* pose_partial;    // [groups][pose_mt][ntiles_n][2 image slots][3]
+    int pose_P, pose_mt;    // output pixels per image (>= tile height), M tiles in the launch
+    int dbg;                // measurement only (DAVO_DBG; results are wrong with any bit set): 1 DMA reads the zero line,
+                            // 2 no matrix phase, 4 no wave-half stagger (32x32x16 form), 32 no epilogue, 64 stores fold onto 256 tiles
+};
+
+constexpr int LDB = 144;        // LDS row: 128 data bytes + 16 pad (conflict-free b128 fragment reads)
+
+template <int WM, int WN, int TM, int TN, int NSTG = 2> struct TileH {
+    static constexpr int THREADS = WM * WN * 64;
+    static constexpr int BMH = WM * TM * 32;
+    static constexpr int BNH = WN * TN * 32;
+    static constexpr int A_LOADS = BMH * 8 / THREADS;
+    static constexpr int B_LOADS = BNH * 8 / THREADS;
+    static constexpr int ROWS_PER_PASS = THREADS / 8;
+    static constexpr int LDS_BYTES = 2 * (BMH + BNH) * LDB;          // register-staged: padded rows
+#ifndef DAVO_H3_STAGES
+#define DAVO_H3_STAGES 2
+#endif
+    // LDS ring slots: 2; the 128x128 tile of a remainder launch (one workgroup per CU, nothing else to hide the DMA
+    // latency behind) takes 3
+    static constexpr int DMA_STAGES = DAVO_H3_STAGES == 2 ? NSTG : DAVO_H3_STAGES;
+    static constexpr int LDS_BYTES_DMA = DMA_STAGES * (BMH + BNH) * 128;   // LDS-DMA ring: linear rows, XOR-swizzled units
+    static_assert(A_LOADS >= 1 && A_LOADS <= 4 && B_LOADS >= 1 && B_LOADS <= 4, "staging shape");
+};
+
+// ---- conv_patch_h3.h (cnv1 from an LDS patch) ---------------------------------------------
+namespace cp1 {
+constexpr int KS = 7, TH = 8, TW = 16;                 // filter, output tile
+constexpr int PH = 2 * TH + KS - 2, PW = 2 * TW + KS - 2;      // 21 x 37 input pixels
+constexpr int UNITS = 32;                              // 16-byte units per (py, parity) row (19 used)
+constexpr int ROWB = UNITS * 16;                       // 512 B
+constexpr int PLANE = PH * 2 * ROWB;                   // 21,504 B per plane (hi / lo)
+constexpr int STEPS = 2 * KS;                          // 14 MFMA steps (8 taps per filter row)
+constexpr int WBYTES = STEPS * 2 * 64 * 16;            // 28,672 B: [step][plane][lane] x 16 B
+constexpr int LDS_BYTES = 2 * PLANE + WBYTES;          // 71,680 B
+constexpr int THREADS = 256;
+}  // namespace cp1
+
+struct ConvPatchParams {
+    const uint8_t* x;       // packed split-fp16 input [NB][H][W][8 hi | 8 lo]
+    const uint8_t* w;       // [14][2][64][8] halves: B fragments in lane order, pre-scaled
+    const float* bias;      // [16]
+    uint8_t* y;             // split-fp16 blocked output [NB][Ho][Wo][16 hi | 16 lo]
+    const uint8_t* zeros;
+    int H, W, Ho, Wo, pad_t, pad_l;
+    int tiles_x, tiles_y, ntiles;
+    float out_scale;
+    float bias_scale;           // accumulator init = bias * bias_scale
+    unsigned* range;            // atomicMax of the stored activations' bit patterns (range monitor); may be null
+    // FUSED = true: the patch is built from the raw inputs (mask + pack fused in, the packed tensor
+    // is never materialised): davo.py:1519-1522 (u8 -> f32), :1115,1178 (LUT attention), :1404-1442
+    const uint8_t* img;     // u8 [B][H][3W][3]
+    const float* flow;      // [B][4][H][W][2]
+    const float* seg;       // [B][3][H][W][1]
+    const float* tab;       // [B][3][19] attention tables (se_excite)
+    Variant v;
+};
+
+}  // namespace davo

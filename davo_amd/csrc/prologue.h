@@ -11,14 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "params.h"
+
 namespace davo {
-
-constexpr int NCLS = 19;
-constexpr int SQ_CHUNKS = 32;       // partial sums per (triplet, source) plane
-
-struct Variant {
-    int cin_per_frame, cnv6_out, se_act, norm_flow, abs_mode, att_source, mask_rgb, mask_info;
-};
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -225,7 +220,6 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
 // Pass 1: grid (PH_SPLIT, 2B images, 2 heads), 256 threads = one per cnv7 channel (coalesced rows);
 // block s sums its slice of the P pixels and writes 3 partial dot products.  Pass 2 (pose_finish)
 // adds the PH_SPLIT partials in a fixed order -> bitwise reproducible.
-constexpr int PH_SPLIT = 8;
 
 __global__ __launch_bounds__(256) void pose_head_partial(const float* __restrict__ c7, int P,
                                                          const float* __restrict__ wpred /*[2][256][3]*/,

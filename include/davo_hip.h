@@ -29,7 +29,8 @@ typedef enum {
     DAVO_ERR_HIP = -2,          /* a HIP runtime call failed                   */
     DAVO_ERR_NOT_READY = -3,    /* forward before every weight was loaded      */
     DAVO_ERR_NOMEM = -4,
-    DAVO_ERR_RANGE = -5         /* f16x3: a layer's activations left the fp16-pair storage range */
+    DAVO_ERR_RANGE = -5,        /* f16x3: a layer's activations left the fp16-pair storage range */
+    DAVO_ERR_COMM = -6          /* librccl could not be loaded, or an RCCL call failed           */
 } davo_status;
 
 /* What the reference derives from the --version string (davo.py:1010-1102,1117-1450);
@@ -75,7 +76,11 @@ int davo_forward(davo_ctx* ctx, int B, const uint8_t* img, const float* flow, co
 
 /* Same computation on device-resident buffers (the path bench.py times; multi-GPU shards keep
  * their windows in HBM).  Asynchronous on the context's stream unless elapsed_ms != NULL, in
- * which case it is bracketed by HIP events, synchronised, and the device time is returned. */
+ * which case it is bracketed by HIP events, synchronised, and the device time is returned.
+ * f16x3 range guard: the asynchronous form cannot know its own result, so the batches issued
+ * since the last davo_synchronize() are judged there (DAVO_ERR_RANGE from davo_synchronize means
+ * one of them left the fp16-pair storage range: see davo_calibrate); the timed, synchronous form
+ * returns DAVO_ERR_RANGE itself. */
 int davo_forward_device(davo_ctx* ctx, int B, const void* d_img, const void* d_flow,
                         const void* d_seg, void* d_pose, float* elapsed_ms);
 
@@ -92,6 +97,9 @@ int davo_host_alloc(int device, size_t bytes, void** out);
 int davo_host_free(void* p);
 int davo_memcpy_h2d(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
 int davo_memcpy_d2h(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* Waits for every stream of the context.  Returns DAVO_ERR_RANGE if an f16x3 batch issued through
+ * davo_forward_device since the previous call left the fp16-pair storage range (poses of those
+ * batches are not float32-grade; the record is reset, so the next call judges later batches only). */
 int davo_synchronize(davo_ctx* ctx);
 /* Run on a caller-owned hipStream_t (NULL restores the context's own stream). */
 int davo_set_stream(davo_ctx* ctx, void* hip_stream);
@@ -151,6 +159,33 @@ int davo_set_activation_shifts(davo_ctx* ctx, const int* shifts);
  *       sub-batch i when B >= 2*host_chunk.  0 = copy the whole batch, then compute.  Results do not change. */
 int davo_set_option(davo_ctx* ctx, const char* key, int value);
 
+/* ---- multi-GPU: the pose gather of the window-sharded sequence driver, on RCCL ---------------
+ * The reference runs one process on one GPU (test_kitti_pose.py:133-149: window loop, then the
+ * sequential 4x4 chain).  Here one process per GPU takes a contiguous window range; the only
+ * exchange is one all-gather of [n,2,6] float32 before the chain.  librccl is loaded on the first
+ * call of this group.  Protocol: rank 0 calls davo_comm_unique_id and ships the DAVO_COMM_ID_BYTES
+ * to the other ranks by any side channel (davo_amd/comm.py: a file), then every rank calls
+ * davo_comm_init with its own context (one GPU per rank: RCCL refuses two ranks on one device).
+ *   davo_allgather_poses: local [n_local,2,6] host floats (n_local <= n_per_rank; the rest of the
+ *     rank's slot is zero-filled) -> all [nranks*n_per_rank,2,6] host floats on every rank, rank r's
+ *     windows at [r*n_per_rank, ...).  elapsed_ms (may be NULL) = device time of the collective alone.
+ *   davo_allgather_poses_device: the same on device buffers (n_per_rank windows in, nranks*n_per_rank
+ *     out), after the context's own streams have drained.
+ *   davo_comm_allreduce: one double, in place; op 0 sum | 1 max | 2 min (bench.py: max-over-ranks).
+ *   davo_comm_barrier: every stream of this context idle, then a rendezvous of all ranks.
+ * Errors: DAVO_ERR_COMM (message names the RCCL call); there is no fallback transport. */
+#define DAVO_COMM_ID_BYTES 128
+int davo_comm_unique_id(void* id_out, char* err, int err_len);
+int davo_comm_init(davo_ctx* ctx, int nranks, int rank, const void* id);
+int davo_comm_size(davo_ctx* ctx, int* nranks, int* rank);
+int davo_allgather_poses(davo_ctx* ctx, const float* local, int n_local, int n_per_rank, float* all,
+                         float* elapsed_ms);
+int davo_allgather_poses_device(davo_ctx* ctx, const void* d_local, int n_per_rank, void* d_all,
+                                float* elapsed_ms);
+int davo_comm_allreduce(davo_ctx* ctx, double* value, int op);
+int davo_comm_barrier(davo_ctx* ctx);
+int davo_comm_destroy(davo_ctx* ctx);
+
 /* ---- test hooks -------------------------------------------------------------------------
  * impl 0 = MFMA implicit-GEMM kernels (default, the product path);
  * impl 1 = one-thread-per-output direct convolution in HIP on the reference's own tensor
@@ -169,6 +204,11 @@ int davo_debug_read(davo_ctx* ctx, const char* tensor, float* host_out, size_t n
 int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin,
                      const float* w, int k, int Cout, const float* bias,
                      int stride, int rate, int relu, int precision, float* y, char* err, int err_len);
+
+/* The launch planner on its own (no GPU needed): how an f16x3 layer of M output rows x npad output
+ * channels (x groups) is issued.  Up to two launches: rows[i] output rows in tiles of tile_bm[i] x
+ * tile_bn[i]; returns the number of launches (1 or 2) or a negative davo_status. */
+int davo_plan_layer(int M, int npad, int groups, int* rows, int* tile_bm, int* tile_bn);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ FORBIDDEN = re.compile(r"^\s*(s_load_|s_buffer_load|s_scratch_load|ds_bpermute|d
 
 def compile_to_asm(out):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                           "-o", out, os.path.join(ROOT, "davo_amd", "csrc", "davo_api.hip")], stderr=subprocess.DEVNULL)
+                           "-o", out, os.path.join(ROOT, "davo_amd", "csrc", "launch_h3.hip")], stderr=subprocess.DEVNULL)
 
 
 def check(path):
@@ -64,7 +64,7 @@ def main():
         nk, nc, problems = check(sys.argv[1])
     else:
         with tempfile.TemporaryDirectory() as d:
-            out = os.path.join(d, "davo_api.s")
+            out = os.path.join(d, "launch_h3.s")
             compile_to_asm(out)
             nk, nc, problems = check(out)
     print("%d 16x16x32 kernels, %d chunk bodies checked, %d problem(s)" % (nk, nc, len(problems)))
