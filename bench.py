@@ -4,12 +4,20 @@
 A "step" is one pass of the hot path (SE squeeze + excite, mask/pack, 8 conv layers, pose head)
 over one batch of synthetic triplets that is already resident in HBM.  At N=1 the workload is
 BASELINE.json configs[1]: batch 32, 128x416, flagship variant
-(dilatedPoseNN-cnv6_128 + se_flow + fc_tanh).  For N>1 every rank runs the same per-GPU batch on
-its own windows (weak scaling, no data-path collective: windows are independent,
-test_kitti_pose.py:134-145); after the timed region the ranks' poses are gathered once over
-RCCL, which is reported separately and is not part of `value`.
+(dilatedPoseNN-cnv6_128 + se_flow + fc_tanh).  For N>1 every rank (one process per GPU) runs the
+same per-GPU batch on its own windows (weak scaling, no data-path collective: windows are
+independent, test_kitti_pose.py:134-145); after the timed region the ranks' poses meet once in an
+RCCL all-gather (davo_amd/comm.py), reported separately and not part of `value`.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--height H --width W]
+
+`--gpus N` with N > 1 starts the N ranks itself (davo_amd/launch.py: a parent that touches no GPU and
+returns non-zero if any rank does); started under `python -m torch.distributed.run --nproc-per-node N`
+the script finds RANK / LOCAL_RANK / WORLD_SIZE already set and runs as that rank.  The timed region is
+bracketed on both sides by davo_comm_barrier (every stream of the rank's context drained, then an RCCL
+all-reduce rendezvous) — the launch contract's barrier + device synchronize without PyTorch — and
+`value` uses the MAX elapsed time over the ranks (RCCL all-reduce).  A failed RCCL init or collective
+is a non-zero exit: there is no other transport.
 """
 import argparse
 import json
@@ -28,18 +36,35 @@ CNV6_MACS_PER_PAIR_128x416 = 2 * 981467136          # rotation + translation cnv
 PEAK_F32_MFMA_TFLOPS = 157.3                         # MI355X_MICROARCH.md: FP32 matrix, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0                        # MI355X_MICROARCH.md: BF16/FP16 matrix, dense
 PEAK_HBM_GBS = 8000.0
+# compulsory HBM bytes of the prologue kernels per triplet at 128x416: se_squeeze reads the two flow
+# planes it reduces; mask_pack reads the u8 strip + 2 flow planes + 2 seg planes and writes the packed PoseNN input
+# (2 pair images x 8 channels x 4 B)
+SQUEEZE_BYTES_128x416 = 851968
+PACK_BYTES_128x416 = 479232 + 851968 + 425984 + 2 * 128 * 416 * 32
 
 
 def usable_cores():
     """host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
+    quota = None
     try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = max(1, min(n, int(int(quota) / int(period))))
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(period)
+            n = max(1, min(n, int(quota)))
     except (OSError, ValueError):
         pass
-    return n
+    return n, quota
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def parse_args():
@@ -59,6 +84,7 @@ def parse_args():
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra 2-in-flight throughput measurement (used for the rocprofv3 passes, so that "
                          "per-kernel statistics are not mixed with overlapped launches)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the strict-float32 leg (roofline_f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="triplets per CPU-baseline pass")
     return ap.parse_args()
@@ -66,40 +92,15 @@ def parse_args():
 
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # parent: start one rank per GPU and wait; this process never touches a GPU
+        from davo_amd.launch import spawn_ranks
+        raise SystemExit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    from davo_amd.comm import RcclComm, world_from_env
+    rank, local_rank, world = world_from_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-
-    import torch                                     # plumbing only: barrier / synchronize / RCCL gather
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    # one rank per GPU; DAVO_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box) folds ranks onto the devices present
-    device_index = local_rank % ndev if os.environ.get("DAVO_BENCH_SHARE_GPU") == "1" else local_rank
-    if device_index >= ndev:
-        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
-    torch.cuda.set_device(device_index)
-    backend = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("DAVO_BENCH_BACKEND", "nccl")        # "nccl" is RCCL on ROCm
-        try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", device_index))
-            else:
-                dist.init_process_group(backend, rank=rank, world_size=world)
-        except Exception as e:                       # noqa: BLE001 — keep the measurement alive on gloo
-            sys.stderr.write("rank %d: %s init failed (%s); falling back to gloo\n" % (rank, backend, e))
-            backend = "gloo"
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-    comm_dev = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
+    device_index = local_rank                        # one rank per GPU
 
     from davo_amd import Engine, synth, parse_version, FLAGSHIP_VERSION
     cfg = parse_version(FLAGSHIP_VERSION)
@@ -109,9 +110,10 @@ def main():
     cnv6_flops_per_launch = 2 * CNV6_MACS_PER_PAIR_128x416 * scale_px * (2 * B)
 
     weights = synth.make_weights(cfg)
-    eng = Engine(cfg, H, W, B, device=device_index)
+    eng = Engine(cfg, H, W, B, device=device_index)  # raises without a GPU: the HIP path has no CPU fallback
     eng.load_weights(weights)
     eng.set_precision(args.precision)
+    comm = RcclComm(eng, rank, world) if world > 1 else None     # raises on any RCCL failure: no gloo, no TCP stand-in
 
     # synthetic windows of this rank's shard, resident in HBM before the timed region; one buffer set per
     # in-flight slot (consecutive steps work on different batches of the shard)
@@ -132,28 +134,33 @@ def main():
     eng.set_inflight(nset)
 
     def sync_all():
+        """barrier + device synchronize: every stream of this rank's context idle (and its f16x3 range record
+        judged: DavoRangeError here means a batch left the fp16-pair range), then all ranks rendezvous"""
         eng.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        eng.synchronize()
-        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+
+    def max_over_ranks(x):
+        return comm.allreduce(x, "max") if comm is not None else x
+
+    def timed(run_steps, steps):
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        sync_all()
+        return max_over_ranks(time.perf_counter() - t0)
 
     for i in range(args.warmup):
         eng.forward_device(B, *sets[i % nset])
     eng.synchronize()
 
     # timed region: K steps; only the dominant kernel (main cnv6 launch) is bracketed by HIP events
-    # on the launch stream, so the event records do not perturb the other 15 launches
+    # on the launch stream, so the event records do not perturb the other launches
     eng.profile(2)
     eng.profile_reset()
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.forward_device(B, *sets[i % nset])
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed_max = timed(lambda k: [eng.forward_device(B, *sets[i % nset]) for i in range(k)], args.steps)
     dominant = eng.profile_entries()
+    plan6 = eng.last_plan(5)                          # [(128-row M tiles, N tile | f16x3 tile id), ...]
     # untimed extra pass, one batch in flight: per-kernel breakdown (every launch bracketed)
     eng.set_inflight(1)
     eng.profile(1)
@@ -162,29 +169,75 @@ def main():
         eng.forward_device(B, d_img, d_flow, d_seg, d_pose)
     kernels = eng.profile_entries()
     eng.profile(False)
+    eng.synchronize()
+    poses = d_pose.download((B, 2, 6))
 
-    # for reference: the bit-exact FP32-MFMA mode on the same batch (short, untimed for `value`)
-    f32_mode = None
-    if args.precision == "f16x3" and world == 1:
+    def roofline_block(precision, dom, plan, avg_key="cnv6"):
+        total_mtiles = sum(m for m, _ in plan)
+        flops_main = cnv6_flops_per_launch * plan[0][0] / total_mtiles
+        n6, ms6 = dom.get(avg_key, (0, 0.0))
+        avg6 = ms6 / max(n6, 1)
+        achieved = flops_main / (avg6 * 1e-3) / 1e12 if avg6 > 0 else 0.0
+        if precision == "f32":
+            peak = PEAK_F32_MFMA_TFLOPS
+            kname = "davo::conv_igemm_f32<3,1,128,6> (cnv6 main launch: rotation|translation fused, N=256, K=2304)"
+            peak_note = "FP32 MFMA dense peak (v_mfma_f32_32x32x2_f32)"
+            key = "conv_igemm_f32<3, 1, 128, 6>"
+        else:
+            # every algorithmic FLOP costs three fp16 MFMA FLOPs (hi*hi, hi*lo, lo*hi), so the
+            # matrix-pipe roofline of this algorithm is the fp16 dense peak / 3
+            peak = PEAK_F16_MFMA_TFLOPS / 3.0
+            tiles = {0: "128x32", 1: "256x64", 2: "256x128", 3: "128x256", 4: "128x128", 5: "256x256", 6: "208x256"}
+            kname = ("davo::conv_igemm_h3<3,1,...,6,true,false,true> (cnv6 main launch: rotation|translation fused, N=256, "
+                     "K=2304, %s tile, LDS-DMA staged, v_mfma_f32_16x16x32_f16)" % tiles.get(plan[0][1], "?"))
+            peak_note = "fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP; frac = matrix-pipe utilisation"
+            key = "conv_igemm_h3<3, 1, "
+        # HBM traffic of the dominant kernel: from the most recent committed PMC pass (profiles/), not live —
+        # rocprofv3 counter collection cannot run inside the timed process
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))):
+                tj = json.load(open(f))
+                if tj.get("batch", 32) != B or (H, W) != (128, 416):
+                    continue
+                hit = [v for k, v in tj["kernels"].items() if key in k and (precision == "f32" or ", 6, true, false" in k)]
+                if hit:
+                    hit.sort(key=lambda v: -(v["read_bytes"] + v["write_bytes"]))
+                    traffic = hit[0]["read_bytes"] + hit[0]["write_bytes"]
+                    traffic_src = "profiles/" + os.path.basename(f)
+                    break
+        except (OSError, ValueError, KeyError):
+            pass
+        return {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                "peak_note": peak_note, "avg_launch_ms": round(avg6, 4), "flops_per_launch": flops_main,
+                "launch_plan": "cnv6 as %s (mtiles of 128 rows, N tile)" % plan}
+
+    # the reference's own arithmetic (float32, nets/posenn.py:205-215 slim.conv2d) as a first-class result:
+    # same batch, same K steps, barrier on both sides, max over ranks, its own roofline against the FP32-MFMA peak
+    f32_block = None
+    if args.precision == "f16x3" and not args.no_f32:
         eng.set_precision("f32")
         for _ in range(2):
             eng.forward_device(B, d_img, d_flow, d_seg, d_pose)
         eng.profile(2)
         eng.profile_reset()
-        eng.synchronize()
-        f0 = time.perf_counter()
-        for _ in range(5):
-            eng.forward_device(B, d_img, d_flow, d_seg, d_pose)
-        eng.synchronize()
-        fdt = time.perf_counter() - f0
-        n32, ms32 = eng.profile_entries().get("cnv6", (0, 0.0))
+        f32_elapsed = timed(lambda k: [eng.forward_device(B, d_img, d_flow, d_seg, d_pose) for _ in range(k)], args.steps)
+        dom32 = eng.profile_entries()
         plan32 = eng.last_plan(5)
-        share = plan32[0][0] / float(sum(m for m, _ in plan32))
-        tf32 = cnv6_flops_per_launch * share / (ms32 / max(n32, 1) * 1e-3) / 1e12 if ms32 > 0 else 0.0
-        f32_mode = {"value": round(B * 5 / fdt, 2), "unit": "triplets/s", "cnv6_tflops": round(tf32, 2),
-                    "cnv6_frac_of_f32_mfma_peak": round(tf32 / PEAK_F32_MFMA_TFLOPS, 4),
-                    "note": "davo_set_precision(0): v_mfma_f32_32x32x2_f32, bit-exact fmaf chains"}
         eng.profile(False)
+        whole32 = flops_per_triplet * B * args.steps / f32_elapsed / 1e12
+        f32_block = roofline_block("f32", dom32, plan32)
+        f32_block.update({"value": round(world * B * args.steps / f32_elapsed, 2), "unit_value": "triplets/s",
+                          "ms_per_step": round(f32_elapsed / args.steps * 1e3, 4), "steps": args.steps, "dtype": "f32",
+                          "whole_path_tflops_per_gpu": round(whole32, 2),
+                          "whole_path_frac_of_mfma_peak": round(whole32 / PEAK_F32_MFMA_TFLOPS, 4),
+                          "note": "davo_set_precision(0): v_mfma_f32_32x32x2_f32, bit-for-bit float32 fmaf chains — the "
+                                  "reference's arithmetic; same batch, steps and bracketing as `value`"})
+        poses32 = d_pose.download((B, 2, 6))
+        f32_block["max_abs_diff_f16x3_vs_f32"] = float(np.abs(poses32 - poses).max())
         eng.set_precision("f16x3")
         eng.forward_device(B, d_img, d_flow, d_seg, d_pose)      # d_pose holds the f16x3 result again
         eng.synchronize()
@@ -202,85 +255,48 @@ def main():
         eng.set_inflight(2)
         for i in range(4):
             eng.forward_device(B, *both[i % 2])
-        sync_all()
-        p0 = time.perf_counter()
-        for i in range(args.steps):
-            eng.forward_device(B, *both[i % 2])
-        sync_all()
-        pdt = time.perf_counter() - p0
-        tp = torch.tensor([pdt], dtype=torch.float64, device=comm_dev)
-        if world > 1:
-            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-        pipelined = {"batches_in_flight": 2, "value": round(world * B * args.steps / float(tp.item()), 2), "unit": "triplets/s",
-                     "ms_per_step": round(float(tp.item()) / args.steps * 1e3, 4),
+        pdt = timed(lambda k: [eng.forward_device(B, *both[i % 2]) for i in range(k)], args.steps)
+        pipelined = {"batches_in_flight": 2, "value": round(world * B * args.steps / pdt, 2), "unit": "triplets/s",
+                     "ms_per_step": round(pdt / args.steps * 1e3, 4),
                      "note": "davo_set_inflight(ctx, 2); same K steps, barrier + synchronize on both sides, max over ranks"}
         eng.set_inflight(1)
         eng.forward_device(B, *sets[0])
         eng.synchronize()
         sets.append(set2)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max = float(t.item())
-
-    poses = d_pose.download((B, 2, 6))
-
-    # one gather of the shard poses (config 4's stitch input) over RCCL, outside the timed region
-    gather_ms, gather_err = None, None
-    if world > 1:
-        try:
-            mine = torch.from_numpy(poses).to(comm_dev)
-            out = [torch.empty_like(mine) for _ in range(world)]
-            torch.cuda.synchronize()
-            g0 = time.perf_counter()
-            dist.all_gather(out, mine)
-            torch.cuda.synchronize()
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            assert torch.equal(out[rank].cpu(), torch.from_numpy(poses))
-        except Exception as e:                       # noqa: BLE001
-            gather_err = "%s: %s" % (type(e).__name__, e)
+    # one all-gather of the shard poses (config 4's stitch input) over RCCL, outside the timed region
+    gather = None
+    if comm is not None:
+        comm.barrier()
+        g0 = time.perf_counter()
+        allp, coll_ms = comm.allgather(poses)
+        wall_ms = (time.perf_counter() - g0) * 1e3
+        if not np.array_equal(allp[rank * B:(rank + 1) * B], poses):
+            raise SystemExit("rank %d: the RCCL all-gather did not return this rank's own poses" % rank)
+        gather = {"backend": "rccl (librccl via davo_allgather_poses)", "bytes_per_rank": int(poses.nbytes),
+                  "collective_ms": round(coll_ms, 4), "wall_ms_incl_staging": round(wall_ms, 3)}
 
     if rank == 0:
         value = world * B * args.steps / elapsed_max
-        # the dominant kernel = the main cnv6 launch (whole rounds of 128x128 tiles); a remainder
-        # launch with narrower tiles, if the planner issued one, is listed as "cnv6.rem"
-        plan6 = eng.last_plan(5)                      # [(128-row M tiles, N tile | f16x3 tile id), ...]
-        total_mtiles6 = sum(m for m, _ in plan6)
-        cnv6_flops_main = cnv6_flops_per_launch * plan6[0][0] / total_mtiles6
-        n6, ms6 = dominant.get("cnv6", (0, 0.0))
-        avg6 = ms6 / max(n6, 1)
-        achieved = cnv6_flops_main / (avg6 * 1e-3) / 1e12 if avg6 > 0 else 0.0
         kern_ms = {k: round(v[1] / max(v[0], 1), 4) for k, v in kernels.items()}
         whole = flops_per_triplet * B * args.steps / elapsed_max / 1e12
-        if args.precision == "f32":
-            peak, dtype = PEAK_F32_MFMA_TFLOPS, "f32"
-            kname = "davo::conv_igemm_f32<3,1,128,6> (cnv6 main launch: rotation|translation fused, N=256, K=2304)"
-            peak_note = "FP32 MFMA dense peak (v_mfma_f32_32x32x2_f32)"
-        else:
-            # every algorithmic FLOP costs three fp16 MFMA FLOPs (hi*hi, hi*lo, lo*hi), so the
-            # matrix-pipe roofline of this algorithm is the fp16 dense peak / 3
-            peak, dtype = PEAK_F16_MFMA_TFLOPS / 3.0, "f16x3 (fp16 hi/lo split operands, 3 MFMA products, f32 accumulate)"
-            tiles = {0: "128x32", 1: "256x64", 2: "256x128", 3: "128x256", 4: "128x128", 5: "256x256"}
-            kname = ("davo::conv_igemm_h3<3,1,...,6,true,false,true> (cnv6 main launch: rotation|translation fused, N=256, "
-                     "K=2304, %s tile, LDS-DMA staged, v_mfma_f32_16x16x32_f16)" % tiles.get(plan6[0][1], "?"))
-            peak_note = "fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP; frac = matrix-pipe utilisation"
-        # HBM traffic of the dominant kernel: from the most recent committed PMC pass (profiles/), not live —
-        # rocprofv3 counter collection cannot run inside the timed process
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-            key = "conv_igemm_f32<3, 1, 128, 6>" if args.precision == "f32" else "conv_igemm_h3<3, 1, 4, 2, 2, 4, 6, true, false"
-            for f in reversed(cands):
-                tj = json.load(open(f))
-                hit = [v for k, v in tj["kernels"].items() if key in k]
-                if hit and (B, H, W) == (32, 128, 416):
-                    traffic = hit[0]["read_bytes"] + hit[0]["write_bytes"]
-                    traffic_src = "profiles/" + os.path.basename(f)
-                    break
-        except (OSError, ValueError, KeyError):
-            pass
+        roof = roofline_block(args.precision, dominant, plan6)
+        dtype = "f32" if args.precision == "f32" else "f16x3 (fp16 hi/lo split operands, 3 MFMA products, f32 accumulate)"
+        # the HBM-bound front of the path: algorithmic bytes / kernel time from the per-kernel breakdown pass
+        sq_ms, mp_ms = kern_ms.get("se_squeeze_partial", 0.0), kern_ms.get("mask_pack", 0.0)
+        pro_bytes = (SQUEEZE_BYTES_128x416 + PACK_BYTES_128x416) * scale_px * B
+        pro = None
+        if sq_ms > 0 and mp_ms > 0:
+            gbs = pro_bytes / ((sq_ms + mp_ms) * 1e-3) / 1e9
+            pro = {"bound": "hbm", "kernels": "se_squeeze_partial + mask_pack<16>", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                   "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_step": int(pro_bytes),
+                   "ms": round(sq_ms + mp_ms, 4),
+                   "parts": {"se_squeeze_partial": {"bytes": int(SQUEEZE_BYTES_128x416 * scale_px * B), "ms": sq_ms,
+                                                    "GB/s": round(SQUEEZE_BYTES_128x416 * scale_px * B / (sq_ms * 1e-3) / 1e9, 1)},
+                             "mask_pack": {"bytes": int(PACK_BYTES_128x416 * scale_px * B), "ms": mp_ms,
+                                           "GB/s": round(PACK_BYTES_128x416 * scale_px * B / (mp_ms * 1e-3) / 1e9, 1)}},
+                   "note": "algorithmic bytes: flow planes 0,1 (squeeze); u8 strip + 2 flow + 2 seg planes in, packed "
+                           "[2B,H,W,8 hi|8 lo] out (mask_pack); peak = 8 TB/s HBM3E spec"}
         res = {
             "metric": "pose-net triplets/sec (128x416x3-frame)" if (H, W) == (128, 416)
                       else "pose-net triplets/sec (%dx%dx3-frame)" % (H, W),
@@ -292,19 +308,14 @@ def main():
                                    "triplets, dilatedPoseNN-cnv6_128 + se_flow + fc_tanh" % (B, H, W),
                        "version": FLAGSHIP_VERSION, "batch_per_gpu": B, "height": H, "width": W,
                        "parallelism": "window-sharded replicas x%d" % world, "batches_in_flight": nset},
-            "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
-                         "traffic_source": traffic_src, "peak_note": peak_note,
-                         "avg_launch_ms": round(avg6, 4), "flops_per_launch": cnv6_flops_main,
-                         "launch_plan": "cnv6 as %s (mtiles of 128 rows, N tile)" % plan6},
+            "roofline": roof,
             "whole_path_tflops_per_gpu": round(whole, 2),
-            "whole_path_frac_of_mfma_peak": round(whole / peak, 4),
+            "whole_path_frac_of_mfma_peak": round(whole / roof["peak"], 4),
+            "roofline_prologue": pro,
             "kernel_avg_ms": kern_ms,
-            "f32_exact_mode": f32_mode,
+            "roofline_f32": f32_block,
             "pipelined": pipelined,
-            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
-            "gather_backend": backend, "gather_error": gather_err,
+            "gather": gather,
         }
         # parity on the bench's own batch (bounded: the first 2 windows) + CPU baseline beside it
         from oracle import c_oracle
@@ -315,7 +326,7 @@ def main():
         res["oracle_note"] = "CPU restatement (TF1 itself cannot run offline: parity unpinned vs TF)"
         if world == 1 and not args.no_cpu_baseline:
             nb = max(1, min(args.cpu_sample, B))
-            cores = usable_cores()
+            cores, quota = usable_cores()
             c_oracle.forward(cfg, img[:1], flow[:1], seg[:1], weights, nthreads=cores)   # warm-up
             c0 = time.perf_counter()
             passes = 0
@@ -325,20 +336,31 @@ def main():
                 if time.perf_counter() - c0 > 30.0:
                     break
             cdt = time.perf_counter() - c0
+            n1 = min(2, B)                                      # one thread: ~0.3 s per triplet
+            s0 = time.perf_counter()
+            c_oracle.forward(cfg, img[:n1], flow[:n1], seg[:n1], weights, nthreads=1)
+            sdt = time.perf_counter() - s0
             res["cpu_baseline"] = {"value": round(nb * passes / cdt, 3), "unit": "triplets/s", "cores": cores,
-                                   "kind": "port",
+                                   "kind": "port", "cpu_model": cpu_model(),
+                                   "host_logical_cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)),
+                                   "cgroup_cpu_quota": quota,
+                                   "one_core": {"value": round(n1 / sdt, 3), "unit": "triplets/s", "cores": 1,
+                                                "sample": "1 pass of %d triplets, 1 thread" % n1},
                                    "sample": "%d passes of %d triplets (%dx%d) of the bench batch through "
-                                             "oracle/davo_oracle.c (f32, OpenMP, -O3 -march=x86-64-v3)" % (passes, nb, H, W)}
+                                             "oracle/davo_oracle.c (f32, OpenMP, -O3 -march=x86-64-v3); `cores` = threads "
+                                             "used = min(affinity mask, cgroup quota) of this process on the GPU box's host"
+                                             % (passes, nb, H, W)}
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
 
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     for st in sets:
         for b in st:
             b.free()
     eng.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -4,8 +4,11 @@ writes ``<seq>-pred_kitti_pose.txt``.
 
     python -m davo_amd.run_kitti_pose --test_seq 3 --concat_img_dir DUMP --ckpt_file W.npz \
         --output_dir out --version v1-...                    # one GPU
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
-        -m davo_amd.run_kitti_pose ... --batch_size 64       # windows sharded over 8 GPUs
+    python -m davo_amd.run_kitti_pose ... --batch_size 64 --gpus 8     # windows sharded over 8 GPUs
+
+With ``--gpus N`` the command starts N ranks of itself, one per GPU (davo_amd/launch.py; a launcher that
+sets RANK / LOCAL_RANK / WORLD_SIZE itself, e.g. ``python -m torch.distributed.run``, works too); the ranks'
+poses meet in one RCCL all-gather (davo_amd/comm.py) and rank 0 writes the trajectory.
 
 ``--ckpt_file`` is a TF V2 checkpoint as the reference's Saver wrote it (prefix, ``.index`` file or the
 directory holding ``checkpoint``; davo_amd/tf_checkpoint.py reads it without TensorFlow) or an ``.npz``
@@ -15,6 +18,7 @@ checkpoint exists offline) and N is the frame count (801 = seq 03, 4541 = seq 00
 """
 import argparse
 import os
+import sys
 import time
 
 import numpy as np
@@ -36,6 +40,7 @@ def main(argv=None):
     ap.add_argument("--ckpt_file", default=None)
     ap.add_argument("--version", default=FLAGSHIP_VERSION)
     ap.add_argument("--synthetic", type=int, default=0, help="frame count of a synthetic sequence")
+    ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node to shard the windows over (one rank per GPU)")
     ap.add_argument("--no_calibrate", action="store_true",
                     help="skip the activation-range calibration of the f16x3 arithmetic (include/davo_hip.h: davo_calibrate)")
     ap.add_argument("--loader_threads", type=int, default=4, help="decode/read threads of the input pipeline (as data_loader.py:283-288; more threads contend on the GIL)")
@@ -43,22 +48,15 @@ def main(argv=None):
                     help="extra JPEG decode processes, for Pillow builds that hold the GIL while decoding; 0 = decode in the loader threads")
     a = ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    device, device_index = None, local_rank
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("DAVO_DIST_BACKEND", "nccl")            # "nccl" is RCCL on ROCm; "gloo" for rehearsals
-        if os.environ.get("DAVO_SHARE_GPU") == "1":                       # several ranks on one card (1-GPU box rehearsal)
-            device_index = local_rank % max(1, torch.cuda.device_count())
-        if backend == "nccl":
-            torch.cuda.set_device(device_index)
-            device = torch.device("cuda", device_index)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    from .comm import RcclComm, world_from_env
+    rank, local_rank, world = world_from_env()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the parent only starts the ranks and waits; it never touches a GPU
+        from .launch import spawn_ranks
+        raise SystemExit(spawn_ranks(["-m", "davo_amd.run_kitti_pose"] + list(sys.argv[1:] if argv is None else argv), a.gpus))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    device_index = local_rank
 
     H, W = a.img_height, a.img_width
     if a.synthetic:
@@ -85,8 +83,9 @@ def main(argv=None):
         # every rank calibrates on the same first windows, so the trajectory does not depend on the world size
         system.calibrate(load(0, min(a.batch_size, n_frames - 2)))
 
+    comm = RcclComm.from_env(system.engine) if world > 1 else None      # collective; fails loudly, no other transport
     t0 = time.perf_counter()
-    traj, poses = S.run_sequence(infer, load, n_frames, a.batch_size, rank, world, device)
+    traj, poses = S.run_sequence(infer, load, n_frames, a.batch_size, rank, world, comm)
     dt = time.perf_counter() - t0
     if rank == 0:
         os.makedirs(a.output_dir, exist_ok=True)
@@ -94,9 +93,9 @@ def main(argv=None):
         S.write_kitti_poses(out, traj)
         print("Done. Please check %s  (%d windows on %d GPU(s) in %.2f s incl. input generation/IO)"
               % (out, n_frames - 2, world, dt))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -7,8 +7,8 @@ R = Rx.Ry.Rz; ``pose_vec2mat`` on ``[rz,ry,rx,tx,ty,tz]``), ``utils/common_utils
 
 The windows of a sequence are independent (each ``[2,6]`` output depends only on its own
 3 frames), so ranks take contiguous window ranges and run them with no data-path collective;
-the only exchange is one gather of ``[n,2,6]`` float32 before the sequential 4x4 chain
-(48 B per window: 218 KB for KITTI seq 00 — latency only, on RCCL over xGMI).
+the only exchange is one all-gather of ``[n,2,6]`` float32 before the sequential 4x4 chain
+(48 B per window: 218 KB for KITTI seq 00 — latency only, on RCCL over xGMI; davo_amd/comm.py).
 """
 import os
 
@@ -145,25 +145,27 @@ def run_shard(infer_fn, load_windows, lo, hi, batch_size):
     return out
 
 
-def gather_poses(local, n_windows, world, rank, device=None):
-    """All ranks -> [Nw,2,6] on every rank.  One all_gather of equal padded counts through
-    torch.distributed (backend "nccl" = RCCL on the GPUs, "gloo" in the CPU tests)."""
+def gather_poses(local, n_windows, world, rank, comm=None):
+    """All ranks -> [Nw,2,6] on every rank: one all-gather of equal padded counts.
+
+    ``comm`` is the run's communicator: ``davo_amd.comm.RcclComm`` (librccl through the C ABI,
+    include/davo_hip.h: davo_allgather_poses) in the product; anything with the same
+    ``allgather(local, n_per_rank) -> (all, ms)`` in the CPU tests of the sharding logic."""
     if world == 1:
         return np.asarray(local, np.float32)
-    import torch
-    import torch.distributed as dist
+    if comm is None:
+        raise ValueError("world size %d needs a communicator (davo_amd.comm.RcclComm)" % world)
     per = -(-n_windows // world)
-    buf = torch.zeros((per, 2, 6), dtype=torch.float32)
-    buf[:local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local, np.float32))
-    if device is not None:
-        buf = buf.to(device)
-    parts = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf)
-    full = torch.cat(parts, 0).cpu().numpy()
-    return full[:n_windows]
+    full, _ = comm.allgather(np.ascontiguousarray(local, np.float32), per)
+    # rank r's slot holds its hi-lo windows first; slots are in rank order = window order
+    parts = []
+    for r in range(world):
+        lo, hi = shard_windows(n_windows, world, r)
+        parts.append(full[r * per:r * per + (hi - lo)])
+    return np.concatenate(parts, 0)
 
 
-def run_sequence(infer_fn, load_windows, n_frames, batch_size, rank=0, world=1, device=None):
+def run_sequence(infer_fn, load_windows, n_frames, batch_size, rank=0, world=1, comm=None):
     """The driver loop of test_kitti_pose.py:133-149, sharded: returns the Nf 4x4 poses on
     every rank (the stitch is cheap and sequential; rank 0 writes the file)."""
     n_windows = n_frames - 2
@@ -171,7 +173,7 @@ def run_sequence(infer_fn, load_windows, n_frames, batch_size, rank=0, world=1, 
     if hasattr(load_windows, "for_range"):               # a loader factory: build this rank's prefetching loader
         load_windows = load_windows.for_range(lo, hi, batch_size)
     local = run_shard(infer_fn, load_windows, lo, hi, batch_size)
-    poses = gather_poses(local, n_windows, world, rank, device)
+    poses = gather_poses(local, n_windows, world, rank, comm)
     return stitch_trajectory(poses), poses
 
 

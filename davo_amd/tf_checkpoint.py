@@ -265,7 +265,7 @@ def load_weights(path):
     return read_checkpoint(path)
 
 
-# ---- writer (tests / export): one shard, uncompressed, same on-disk structure as TF's -----------
+# ---- writer (tests / export): uncompressed, same on-disk structure as TF's ------------------------
 def _build_block(items, restart_interval=16):
     buf, restarts, last, n = bytearray(), [], b"", 0
     for k, v in items:
@@ -285,23 +285,29 @@ def _build_block(items, restart_interval=16):
     return bytes(buf)
 
 
-def write_checkpoint(prefix, variables, block_entries=4):
-    """Write {name: ndarray} as <prefix>.index / .data-00000-of-00001 and a `checkpoint' state file."""
+def write_checkpoint(prefix, variables, block_entries=4, num_shards=1):
+    """Write {name: ndarray} as <prefix>.index / .data-SSSSS-of-NNNNN and a `checkpoint' state file.
+    num_shards > 1 spreads the tensors round-robin over that many data files, as a sharded Saver does."""
     names = sorted(variables)
-    data, items = bytearray(), [(b"", b"\x08\x01" + b"\x1a\x02\x08\x01")]      # num_shards=1, version{producer=1}
-    for name in names:
+    data = [bytearray() for _ in range(num_shards)]
+    items = [(b"", b"\x08" + _put_varint(num_shards) + b"\x1a\x02\x08\x01")]      # num_shards, version{producer=1}
+    for i, name in enumerate(names):
         a = np.asarray(variables[name], order="C")          # (ascontiguousarray would turn a scalar into shape (1,))
         raw = a.astype(a.dtype.newbyteorder("<")).tobytes()
         shape = b"".join(b"\x12" + _put_varint(len(d)) + d for d in
                          (b"\x08" + _put_varint(int(s)) for s in a.shape))
         e = b"\x08" + _put_varint(_DT_INV[a.dtype]) + b"\x12" + _put_varint(len(shape)) + shape
-        if len(data):
-            e += b"\x20" + _put_varint(len(data))
+        shard = i % num_shards
+        if shard:
+            e += b"\x18" + _put_varint(shard)
+        if len(data[shard]):
+            e += b"\x20" + _put_varint(len(data[shard]))
         e += b"\x28" + _put_varint(len(raw)) + b"\x35" + struct.pack("<I", _mask_crc(crc32c(raw)))
         items.append((name.encode(), e))
-        data += raw
-    with open(prefix + ".data-00000-of-00001", "wb") as f:
-        f.write(bytes(data))
+        data[shard] += raw
+    for sh in range(num_shards):
+        with open("%s.data-%05d-of-%05d" % (prefix, sh, num_shards), "wb") as f:
+            f.write(bytes(data[sh]))
     with open(prefix + ".index", "wb") as f:
         index = []
 

@@ -88,6 +88,25 @@ def test_run_shard_pads_and_drops():
     assert np.array_equal(out[:, 0, 0], np.arange(3, 10))    # and the padded outputs are dropped
 
 
+class GlooComm:
+    """Test stand-in with RcclComm's allgather contract (davo_amd/comm.py) over gloo on CPU: the product gathers
+    through librccl (davo_allgather_poses), which needs one GPU per rank; the sharding logic around it does not."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def allgather(self, local, n_per_rank=None):
+        import torch
+        import torch.distributed as dist
+        local = np.ascontiguousarray(local, np.float32).reshape(-1, 2, 6)
+        per = local.shape[0] if n_per_rank is None else n_per_rank
+        buf = torch.zeros((per, 2, 6), dtype=torch.float32)
+        buf[:local.shape[0]] = torch.from_numpy(local)
+        parts = [torch.empty_like(buf) for _ in range(self.world)]
+        dist.all_gather(parts, buf)
+        return torch.cat(parts, 0).numpy(), 0.0
+
+
 def _rank_main(rank, world, port, n_frames, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -97,7 +116,7 @@ def _rank_main(rank, world, port, n_frames, q):
     cfg = parse_version(FLAGSHIP_VERSION)
     weights = synth.make_weights(cfg)
     infer = lambda img, flow, seg: c_oracle.forward(cfg, img, flow, seg, weights, nthreads=2)   # noqa: E731
-    traj, poses = S.run_sequence(infer, S.synthetic_window_loader(32, 64), n_frames, 3, rank, world)
+    traj, poses = S.run_sequence(infer, S.synthetic_window_loader(32, 64), n_frames, 3, rank, world, GlooComm(rank, world))
     if rank == 0:
         q.put((np.array(traj), poses))
     dist.destroy_process_group()
@@ -125,3 +144,110 @@ def test_two_rank_gloo_matches_single_process(c_oracle):
     assert poses2.shape == (11, 2, 6)
     assert np.array_equal(poses1, poses2)                    # sharding changes nothing, bit for bit
     assert np.array_equal(np.array(traj1), traj2)
+
+
+def test_gather_needs_a_communicator_and_orders_ragged_shards():
+    """world > 1 without a communicator is an error (no silent single-rank result); the padded slots of ragged
+    shards are dropped in rank order."""
+    with pytest.raises(ValueError):
+        S.gather_poses(np.zeros((3, 2, 6), np.float32), 5, 2, 0, None)
+
+    class Fake:
+        def allgather(self, local, per):
+            assert per == 3 and local.shape == (3, 2, 6)
+            full = np.zeros((6, 2, 6), np.float32)
+            full[0:3, 0, 0] = [0, 1, 2]
+            full[3:5, 0, 0] = [3, 4]
+            full[5] = -99.0                                  # padding of the short last shard
+            return full, 0.0
+    got = S.gather_poses(np.zeros((3, 2, 6), np.float32), 5, 2, 0, Fake())
+    assert got.shape == (5, 2, 6) and list(got[:, 0, 0]) == [0, 1, 2, 3, 4]
+
+
+_CHILD = """
+import os, sys
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.path.isdir(os.environ["DAVO_COMM_DIR"])
+open(os.path.join(sys.argv[1], "rank%d" % rank), "w").write(os.environ["DAVO_COMM_DIR"])
+sys.exit(int(sys.argv[2]) if rank == int(sys.argv[3]) else 0)
+"""
+
+
+def test_spawn_ranks_sets_the_launch_contract_and_fails_if_any_rank_fails(tmp_path):
+    from davo_amd.launch import spawn_ranks
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD)
+    assert spawn_ranks([str(script), str(tmp_path), "0", "0"], 3) == 0
+    dirs = {open(tmp_path / ("rank%d" % r)).read() for r in range(3)}
+    assert len(dirs) == 1 and not os.path.exists(dirs.pop())          # one fresh rendezvous directory, removed afterwards
+    assert spawn_ranks([str(script), str(tmp_path), "7", "1"], 3) == 7  # rank 1 exits 7 -> the run is a failure
+
+
+def test_bench_and_cli_parents_do_not_load_the_hip_library():
+    """`bench.py --gpus N` / `run_kitti_pose --gpus N` parents only spawn ranks: importing what they import must not
+    load libdavo_hip.so (a process that initialised a GPU must not fan out into ranks)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import davo_amd.launch, davo_amd.comm, davo_amd.run_kitti_pose; "
+            "from davo_amd import _lib; assert _lib._lib is None; "
+            "assert not any('libdavo_hip' in l for l in open('/proc/self/maps'))" % os.path.dirname(HERE))
+    subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_comm_rendezvous_path_prefers_the_launcher_directory(monkeypatch, tmp_path):
+    from davo_amd import comm
+    monkeypatch.delenv("DAVO_COMM_FILE", raising=False)
+    monkeypatch.setenv("DAVO_COMM_DIR", str(tmp_path))
+    assert comm.rendezvous_path() == str(tmp_path / "rccl_id")
+    monkeypatch.delenv("DAVO_COMM_DIR")
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    p = comm.rendezvous_path()
+    assert str(os.getppid()) in p and "29511" in p           # ranks of one torch.distributed.run share parent and port
+    monkeypatch.setenv("DAVO_COMM_FILE", "/x/y")
+    assert comm.rendezvous_path() == "/x/y"
+
+
+# ---- row f1 pinned to reference-held code and fixtures ---------------------------------------------------
+STITCH_GOLDEN = os.path.join(HERE, "golden", "stitch_golden.json")
+GT03_FLIP = os.path.join(HERE, "golden", "kitti_gt_poses_03_flip.txt")
+
+
+def test_pose_vec2mat_matches_the_reference_module():
+    """tests/golden/stitch_golden.json: outputs of the reference's own data/kitti/pose_evaluation_utils.py
+    (euler2mat :218-311, pose_vec2mat :359-370), generated in the build container by make_stitch_golden.py."""
+    import json
+    g = json.load(open(STITCH_GOLDEN))
+    vecs, want = np.array(g["vectors"]), np.array(g["matrices"])
+    assert vecs.shape == (62, 6) and want.shape == (62, 4, 4)
+    assert np.abs(S.pose_vec2mat(vecs, np.float64) - want).max() < 1e-14
+    assert np.abs(S.pose_vec2mat(vecs.astype(np.float32)) - want).max() < 2e-6       # the TF graph's float32 (test_kitti_pose.py:122-123)
+    back = S.mat2pose_vec(want[:24])                       # KITTI-sized motions invert exactly
+    assert np.abs(back - vecs[:24]).max() < 1e-12
+
+
+def test_stitch_chain_matches_the_reference_functions():
+    import json
+    g = json.load(open(STITCH_GOLDEN))
+    poses, want = np.array(g["chain_poses"]), np.array(g["chain_trajectory"])
+    assert poses.shape == (40, 2, 6) and want.shape == (42, 4, 4)
+    got = np.array(S.stitch_trajectory(poses, mat_dtype=np.float64))
+    assert np.abs(got - want).max() < 1e-12
+    got32 = np.array(S.stitch_trajectory(poses))           # float32 matrices, float64 chain, like the reference driver
+    assert np.abs(got32 - want).max() < 5e-5
+
+
+def test_mirrored_ground_truth_fixture_seq03():
+    """kitti_benchmark/data/odometry/poses-flip/03-flip.txt (data fixture, in the reference writer's own
+    str(float) format): the mirrored ground truth S.T.S, S = diag(-1,1,1,1), up to the float32 chain drift of
+    whatever produced it (the file is 2.64e-3 away from S.GT.S itself; SURVEY.md §4 quotes 2.6e-3).  GT -> relative poses -> our stitch -> mirror must land on it."""
+    flip = S.read_kitti_poses(GT03_FLIP)
+    gt = S.read_kitti_poses(GT03)
+    assert flip.shape == gt.shape == (801, 4, 4)
+    lines = open(GT03_FLIP).read().splitlines()
+    assert lines[0] == "1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0 0.0"         # the writer's first line, verbatim
+    traj = np.array(S.stitch_trajectory(S.relative_pose_vectors(gt), mat_dtype=np.float64))
+    Sm = np.diag([-1.0, 1.0, 1.0, 1.0])
+    mirrored = Sm @ traj @ Sm
+    assert np.abs(mirrored - flip).max() < 2.7e-3
+    assert np.abs(mirrored - flip).max() <= np.abs(Sm @ gt @ Sm - flip).max() + 1e-4   # no further from it than the GT is
+    assert np.abs(traj - flip).max() > 0.1                 # and it is not the unmirrored trajectory

@@ -100,3 +100,34 @@ def test_entries_the_path_never_needs_are_skipped_not_fatal(tmp_path, monkeypatc
     assert list(got) == ["pose_exp_net/cnv1/biases"]
     with pytest.raises(ValueError, match="unsupported dtype"):
         T.read_checkpoint(prefix, names=["global_step"])
+
+
+def test_sharded_bundle_with_training_slots(tmp_path):
+    """What a training run leaves behind (davo.py:865-867 saves trainable variables + global_step; Adam keeps two slot
+    variables per weight; a sharded Saver writes data-0000N-of-0000M): the reader follows each entry's shard_id, and
+    loading the weights of the path ignores everything the variant does not name."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    weights = synth.make_weights(cfg)
+    everything = dict(weights)
+    everything["global_step"] = np.array(123456, np.int64)
+    everything["beta1_power"] = np.array(0.5, np.float32)
+    for k, v in weights.items():
+        everything[k + "/Adam"] = np.full_like(v, 0.25)
+        everything[k + "/Adam_1"] = np.full_like(v, 4.0)
+    prefix = str(tmp_path / "model-123456")
+    T.write_checkpoint(prefix, everything, num_shards=3)
+    for sh in range(3):
+        assert os.path.getsize("%s.data-%05d-of-00003" % (prefix, sh)) > 0
+    assert not os.path.exists(prefix + ".data-00000-of-00001")
+    got = T.read_checkpoint(str(tmp_path), verify_crc=True)              # via the `checkpoint' state file
+    assert set(got) == set(everything)
+    for n, a in weights.items():
+        assert np.array_equal(got[n], a), n
+        assert float(got[n + "/Adam"].ravel()[0]) == 0.25 and float(got[n + "/Adam_1"].ravel()[0]) == 4.0
+    # the engine-side filter: exactly the variant's 26 tensors are taken, by name
+    want = weight_shapes(cfg)
+    assert set(want) <= set(got) and len(want) == 26
+    # a data shard that went missing is an error, not a silent partial restore
+    os.remove(prefix + ".data-00002-of-00003")
+    with pytest.raises(FileNotFoundError):
+        T.read_checkpoint(prefix)
