@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libdavo_oracle.so")
+# DAVO_ORACLE_SO: another build of the same file (the sanitizer build of tests/test_oracle.py::test_c_oracle_asan)
+_SO = os.environ.get("DAVO_ORACLE_SO") or os.path.join(_HERE, "libdavo_oracle.so")
 
 WEIGHT_ORDER = (
     ["pose_exp_net/%s/%s" % (l, k) for l in ("cnv1", "cnv2", "cnv3", "cnv4", "cnv5")

@@ -75,3 +75,22 @@ def test_counted_lds_waits_are_safe_in_the_compiled_code():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_launch_planner_covers_every_row(built):
+    """davo_plan_layer (host logic, no GPU): whatever the layer size, the launches of a plan cover the M output rows
+    exactly once in order, with tiles that divide the padded channel count; a launch that is not the last ends on a
+    tile boundary of the NEXT launch's tile height (the kernels address tiles from row 0 of the layer)."""
+    L = ctypes.CDLL(built)
+    L.davo_plan_layer.argtypes = [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int)] * 3
+    for M in (1, 7, 128, 3328, 2 * 3328, 13 * 3328 + 5, 64 * 3328, 256 * 3328, 64 * 832, 128 * 13312):
+        for npad, groups in ((32, 1), (64, 1), (128, 1), (256, 1), (256, 2)):
+            rows, bm, bn = (ctypes.c_int * 2)(), (ctypes.c_int * 2)(), (ctypes.c_int * 2)()
+            n = L.davo_plan_layer(M, npad, groups, rows, bm, bn)
+            assert n in (1, 2), (M, npad, groups, n)
+            assert sum(rows[i] for i in range(n)) == M
+            for i in range(n):
+                assert rows[i] > 0 and bm[i] > 0 and npad % bn[i] == 0
+            if n == 2:
+                assert rows[0] % bm[0] == 0 and rows[0] % bm[1] == 0
+    assert L.davo_plan_layer(0, 256, 1, rows, bm, bn) < 0 and L.davo_plan_layer(100, 48, 1, rows, bm, bn) < 0

@@ -619,34 +619,51 @@ def test_sharded_driver_with_rccl_world_of_one(tmp_path, monkeypatch, c_oracle):
 # ---- BASELINE.json configurations as tests (shapes of configs[0], [3], [4]) ---------------------------
 def test_config1_seq03_shape_801_frames(tmp_path, c_oracle):
     """configs[0] plumbing at full length: 801 frames -> 799 windows, batch 1, 128x416 -> an 801-line
-    03-pred_kitti_pose.txt (test_kitti_pose.py:133-153, run_inference.sh:44-51).  A sampled subset of the windows is
-    checked against the oracle, and the file against the stitch of the engine's own poses."""
+    03-pred_kitti_pose.txt (test_kitti_pose.py:133-153, run_inference.sh:44-51).  The file is checked window by
+    window on a sample: consecutive trajectory poses differ by inv(T(tgt->src1)) of that window (:145-149), and the
+    first step is T(tgt->src0) of window 0 (:143-144), both from the oracle's poses of the same synthetic windows."""
     from davo_amd import run_kitti_pose, sequence as S
     run_kitti_pose.main(["--synthetic", "801", "--output_dir", str(tmp_path), "--test_seq", "3", "--batch_size", "1"])
     lines = open(str(tmp_path / "03-pred_kitti_pose.txt")).read().splitlines()
     assert len(lines) == 801 and all(len(l.split(" ")) == 12 for l in lines)
-    got = S.read_kitti_poses(str(tmp_path / "03-pred_kitti_pose.txt"))
+    assert lines[0] == "1.0 0.0 0.0 0.0 0.0 1.0 0.0 0.0 0.0 0.0 1.0 0.0"
+    traj = S.read_kitti_poses(str(tmp_path / "03-pred_kitti_pose.txt"))
     cfg = parse_version(FLAGSHIP_VERSION)
     weights = synth.make_weights(cfg)
-    e = _engine(cfg, 128, 416, 1, weights, "f16x3")
     load = S.synthetic_window_loader(128, 416)
-    e.calibrate(*load(0, 1))                                 # as the CLI does on its first window
-    poses = S.run_shard(e.forward, load, 0, 799, 1)
-    assert np.abs(got - np.array(S.stitch_trajectory(poses))).max() < 1e-9
-    for w in (0, 1, 137, 400, 798):                          # sampled windows vs the oracle
-        assert_pose_close(poses[w:w + 1], c_oracle.forward(cfg, *load(w, w + 1), weights), "window %d" % w)
-    e.close()
+    for w in (0, 1, 137, 400, 798):
+        want = c_oracle.forward(cfg, *load(w, w + 1), weights)[0]           # [2,6]
+        step = np.linalg.inv(traj[w + 1]) @ traj[w + 2]
+        assert np.abs(step - np.linalg.inv(S.pose_vec2mat(want[1:2], np.float64)[0])).max() < 2e-4, w
+        if w == 0:
+            assert np.abs(traj[1] - S.pose_vec2mat(want[0:1], np.float64)[0]).max() < 2e-4
+
+
+class _CachedWindows:
+    """window w -> one of `n` distinct synthetic windows (generating 4,539 distinct 128x416 windows takes minutes
+    of host time and is not what these tests are about)."""
+
+    def __init__(self, H, W, n=64, first_window=0):
+        self.n = n
+        self.img, self.flow, self.seg = synth.make_inputs(n, H, W, first_window=first_window)
+
+    def index(self, w):
+        return (w * 37) % self.n
+
+    def __call__(self, s, e):
+        idx = [self.index(w) for w in range(s, e)]
+        return self.img[idx], self.flow[idx], self.seg[idx]
 
 
 def test_config4_eight_shards_equal_one(c_oracle):
     """configs[3] shape (seq 00: 4541 frames -> 4539 windows, 8 contiguous shards of 568/563, batch 64): the eight
-    shards run one after another on this GPU and concatenated are bit-identical to the 1-shard run; a sample of
-    windows across shard boundaries matches the oracle.  (The 8-GPU run itself is the driver's.)"""
+    shards run one after another on this GPU and concatenated equal the 1-shard run; windows either side of shard
+    boundaries match the oracle.  (The 8-GPU run itself is the driver's.)"""
     from davo_amd import sequence as S
     cfg = parse_version(FLAGSHIP_VERSION)
     weights = synth.make_weights(cfg)
     H, W, B, nw = 128, 416, 64, 4539
-    load = S.synthetic_window_loader(H, W)
+    load = _CachedWindows(H, W, 64)
     e = _engine(cfg, H, W, B, weights, "f16x3")
     one = S.run_shard(e.forward, load, 0, nw, B)
     parts = []
@@ -658,7 +675,7 @@ def test_config4_eight_shards_equal_one(c_oracle):
     # same windows in other batch positions: the fused pose head sums tiles in a fixed order per image, so equal to
     # float32 rounding (tests above), not necessarily to the bit
     assert np.abs(eight - one).max() <= 1e-6 * np.abs(one).max()
-    assert np.array_equal(np.array(S.stitch_trajectory(eight)).shape, (4541, 4, 4))
+    assert np.array(S.stitch_trajectory(eight)).shape == (4541, 4, 4)
     for w in (0, 567, 568, 3975, 3976, 4538):
         assert_pose_close(eight[w:w + 1], c_oracle.forward(cfg, *load(w, w + 1), weights), "window %d" % w)
     e.close()

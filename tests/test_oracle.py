@@ -1,5 +1,7 @@
 """The oracle itself: numpy-f64 vs C-f32 vs torch-CPU conv2d, TF SAME-padding facts, and the
 committed golden outputs.  (Parity with TF1 is unpinned — see oracle/davo_oracle.py.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -139,3 +141,34 @@ def test_whole_posenet_vs_torch():
         outs.append(conv(c7, p + "pred", 1, 1, relu=False).mean(dim=(2, 3)))
     pose = (0.01 * torch.cat(outs, dim=1)).numpy().reshape(B, 2, 6)
     assert np.abs(pose - np.array(g["pose"])).max() < 1e-12
+
+
+def test_c_oracle_asan(tmp_path):
+    """oracle/Makefile's sanitizer build (-fsanitize=address,undefined) of the C restatement on the shapes that
+    stress its indexing: minimum frame, ragged sizes with asymmetric SAME padding, ignore labels, both variants'
+    channel counts.  The checker itself must be memory-clean (sanitizers on the CPU build only)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "libdavo_oracle_asan.so"])
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from davo_amd import synth, parse_version, FLAGSHIP_VERSION\n"
+        "from oracle import c_oracle, davo_oracle as O\n"
+        "for version, (B, H, W) in ((FLAGSHIP_VERSION, (1, 16, 16)), (FLAGSHIP_VERSION, (2, 20, 36)),\n"
+        "                           ('v1-decay100k-sharedNN-dilatedPoseNN-cnv6_64-no_segmask', (1, 16, 20))):\n"
+        "    cfg = parse_version(version); w = synth.make_weights(cfg)\n"
+        "    img, flow, seg = synth.make_inputs(B, H, W)\n"
+        "    seg[0, :, :4, :4] = 255.0; seg[0, 0, 5, 5] = -3.0; seg[0, 2, 6, 6] = np.nan\n"
+        "    got = c_oracle.forward(cfg, img, flow, seg, w, nthreads=2)\n"
+        "    want = O.forward(cfg, img, flow, seg, w)\n"
+        "    assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-3), version\n"
+        "x = np.random.RandomState(3).randn(2, 9, 11, 4).astype(np.float32)\n"
+        "k = np.random.RandomState(4).randn(3, 3, 4, 5).astype(np.float32)\n"
+        "y = c_oracle.conv2d_same(x, k, np.zeros(5, np.float32), 2, 3, True); assert y.shape == (2, 5, 6, 5)\n"
+        "print('asan ok')\n" % root)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
+               DAVO_ORACLE_SO=os.path.join(root, "oracle", "libdavo_oracle_asan.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "asan ok" in out.stdout, (out.stdout + out.stderr)[-3000:]
