@@ -127,14 +127,14 @@ int davo_weights_missing(davo_ctx* c) {
     return n;
 }
 
-// read the range record of the f16x3 forwards issued since the last check, reset it, and judge it
-// (forward.hip: check_range).  Called with every stream of the context idle.
+// read the range record of the f16x3 forwards issued since the last check and judge it (forward.hip:
+// check_range).  Called with every stream of the context idle.  The first batch issued afterwards starts a
+// fresh record (davo_forward_device / davo_forward).
 static int consume_range_record(davo_ctx* c) {
     if (!c->range_dirty || !c->d_range) return DAVO_OK;
     unsigned raw[6];
     HIP_TRY(c, hipMemcpy(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned)));
-    c->range_dirty = false;
+    c->range_dirty = false;            // judged; the record itself stays readable (davo_activation_range) until the next batch
     return check_range(c, raw);
 }
 
@@ -144,8 +144,10 @@ int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flo
     // rotate through the in-flight slots: this batch runs on its own stream and workspace
     activate_slot(c, c->next_slot);
     c->next_slot = (c->next_slot + 1) % c->inflight;
-    if (!elapsed_ms) return forward_device(c, B, d_img, d_flow, d_seg, d_pose);
     HIP_TRY(c, hipSetDevice(c->device));
+    // first batch since the last verdict: no unjudged batch is in flight, so the record can start afresh
+    if (!c->range_dirty && c->d_range) HIP_TRY(c, hipMemsetAsync(c->d_range, 0, 8 * sizeof(unsigned), c->stream));
+    if (!elapsed_ms) return forward_device(c, B, d_img, d_flow, d_seg, d_pose);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = DAVO_OK;
     auto hip_ok = [&](hipError_t e, const char* what) {
@@ -212,8 +214,7 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
     unsigned raw[6];
     HIP_TRY(c, hipMemcpyAsync(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned)));
-    c->range_dirty = false;
+    c->range_dirty = false;                                   // judged here
     return c->last_precision == 1 ? check_range(c, raw) : DAVO_OK;
 }
 

@@ -99,7 +99,8 @@ int davo_memcpy_h2d(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
 int davo_memcpy_d2h(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* Waits for every stream of the context.  Returns DAVO_ERR_RANGE if an f16x3 batch issued through
  * davo_forward_device since the previous call left the fp16-pair storage range (poses of those
- * batches are not float32-grade; the record is reset, so the next call judges later batches only). */
+ * batches are not float32-grade; the next batch starts a fresh record, so the next call judges later
+ * batches only). */
 int davo_synchronize(davo_ctx* ctx);
 /* Run on a caller-owned hipStream_t (NULL restores the context's own stream). */
 int davo_set_stream(davo_ctx* ctx, void* hip_stream);
