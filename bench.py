@@ -81,6 +81,8 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches kept in flight on the GPU in the timed region (davo_set_inflight).  Default 1: one "
                          "batch at a time, so the event-bracketed kernel durations are the kernels' own")
+    ap.add_argument("--cu-partition", action="store_true",
+                    help="with --inflight n: slot i's stream is CU-masked to its own 1/n of every XCD's CUs (davo_set_option cu_partition)")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra 2-in-flight throughput measurement (used for the rocprofv3 passes, so that "
                          "per-kernel statistics are not mixed with overlapped launches)")
@@ -132,6 +134,8 @@ def main():
             img, flow, seg = img_k, flow_k, seg_k
     d_img, d_flow, d_seg, d_pose = sets[0]
     eng.set_inflight(nset)
+    if args.cu_partition:
+        eng.set_option("cu_partition", 1)
 
     def sync_all():
         """barrier + device synchronize: every stream of this rank's context idle (and its f16x3 range record

@@ -397,6 +397,30 @@ int davo_last_plan(davo_ctx* c, int layer, int launch, int* mtiles, int* bn) {
     return DAVO_OK;
 }
 
+// (Re)create the slots' streams.  With cu_partition on, slot i of n gets the CUs [i*32/n, (i+1)*32/n) of EVERY XCD
+// (hipExtStreamCreateWithCUMask; mask bit b = CU b/8 of XCD b%8, and a mask must leave no XCD empty — probed with
+// tools/exp/cumask_probe.hip), so batches in different slots run side by side on disjoint CUs and the write bursts of
+// one overlap the matrix phases of the other.  The launch planner then sizes rounds for 256/n CUs.
+static int rebuild_slot_streams(davo_ctx* c, int n) {
+    for (int i = 0; i < (int)c->slots.size(); ++i) {
+        Slot& s = c->slots[i];
+        if (s.stream) { HIP_TRY(c, hipStreamDestroy(s.stream)); s.stream = nullptr; }
+        if (c->cu_partition && n > 1 && i < n) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int lo = i * 32 / n, hi = (i + 1) * 32 / n;                 // CU indices inside an XCD
+            for (int b = 0; b < 256; ++b)
+                if (b / 8 >= lo && b / 8 < hi) mask[b / 32] |= 1u << (b % 32);
+            HIP_TRY(c, hipExtStreamCreateWithCUMask(&s.stream, 8, mask));
+        } else {
+            HIP_TRY(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        }
+    }
+    c->own_stream = c->slots[0].stream;
+    c->ncu = (c->cu_partition && n > 1) ? 256 / n : 256;
+    activate_slot(c, 0);
+    return DAVO_OK;
+}
+
 int davo_set_inflight(davo_ctx* c, int n) {
     if (!c || n < 1 || n > 4) return fail(c, DAVO_ERR_INVALID, "inflight must be 1..4");
     if (n > 1 && c->user_stream) return fail(c, DAVO_ERR_INVALID, "in-flight slots use the context's own streams: clear davo_set_stream first");
@@ -409,6 +433,7 @@ int davo_set_inflight(davo_ctx* c, int n) {
     }
     c->inflight = n;
     c->next_slot = 0;
+    if (c->cu_partition || c->ncu != 256) { int rc = rebuild_slot_streams(c, n); if (rc) return rc; }
     return DAVO_OK;
 }
 
@@ -417,6 +442,19 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     const std::string k = key;
     if (k == "fuse_pose") c->opt_fuse_pose = value != 0;
     else if (k == "fuse_pack") c->opt_fuse_pack = value != 0;
+    else if (k == "force_tile") {
+        // test hook: every f16x3 layer the tile fits runs as ONE launch of that tile shape (plan.h tile ids; -1 = planner)
+        if (value < -1 || value >= NUM_TILES) return fail(c, DAVO_ERR_INVALID, "force_tile must be -1..%d", NUM_TILES - 1);
+        for (auto& L : c->L) L.tile_h = (value >= 0 && L.cout >= tile_shape(value).bn) ? value : -1;
+    }
+    else if (k == "cu_partition") {
+        if (c->user_stream) return fail(c, DAVO_ERR_INVALID, "cu_partition uses the context's own streams: clear davo_set_stream first");
+        HIP_TRY(c, hipSetDevice(c->device));
+        { int rc = sync_all_slots(c); if (rc) return rc; }
+        c->cu_partition = value != 0;
+        int rc = rebuild_slot_streams(c, c->inflight);
+        if (rc) return rc;
+    }
     else if (k == "host_chunk") { if (value < 0) return fail(c, DAVO_ERR_INVALID, "host_chunk must be >= 0"); c->host_chunk = value; }
     else return fail(c, DAVO_ERR_INVALID, "unknown option `%s'", key);
     return DAVO_OK;
@@ -485,7 +523,7 @@ int davo_debug_read(davo_ctx* c, const char* tensor, float* host_out, size_t n_f
 
 int davo_plan_layer(int M, int npad, int groups, int* rows, int* tile_bm, int* tile_bn) {
     if (M < 1 || npad < 32 || npad % 32 || groups < 1 || !rows || !tile_bm || !tile_bn) return DAVO_ERR_INVALID;
-    const std::vector<LaunchH> plan = plan_layer_h3(M, npad, groups, -1);
+    const std::vector<LaunchH> plan = plan_layer_h3(M, npad, groups, -1, npad == 256);
     if (plan.empty() || plan.size() > 2) return DAVO_ERR_INVALID;
     for (size_t i = 0; i < plan.size(); ++i) {
         const TileShape ts = tile_shape(plan[i].tile);

@@ -68,6 +68,8 @@ struct davo_ctx {
     int device = 0, H = 0, W = 0, max_batch = 0;
     std::vector<davo::Slot> slots;             // slots[0] is created by davo_create
     int inflight = 1, next_slot = 0;
+    int ncu = 256;                             // compute units a launch of this context may use (CU-masked slot streams: 256 / slots)
+    bool cu_partition = false;                 // davo_set_option "cu_partition": slot i's stream is masked to its own share of every XCD's CUs
     bool user_stream = false;
     bool opt_fuse_pose = true;                 // f16x3: pose head fused into cnv7's epilogue (davo_set_option)
     bool opt_fuse_pack = false;                // f16x3: mask+pack fused into cnv1's patch fill

@@ -117,7 +117,7 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
         p.g_w = (long)L.npad * L.kpad; p.g_bias = L.npad;
     }
     const int mtiles = (p.M + BM - 1) / BM;
-    const std::vector<Launch> plan = plan_layer(mtiles, L.npad, L.groups);
+    const std::vector<Launch> plan = plan_layer(mtiles, L.npad, L.groups, c->ncu);
     c->last_plan[li][0] = c->last_plan[li][1] = 0;
     for (size_t i = 0; i < plan.size(); ++i) {
         p.mtile0 = plan[i].mtile0;
@@ -160,10 +160,11 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         p.g_w = (long)L.npad_h * p.w_row_bytes; p.g_bias = L.npad_h;
     }
     if (const char* e = tuning_env("DAVO_DBG")) p.dbg = atoi(e);       // tuning build only
-    std::vector<LaunchH> plan = plan_layer_h3(p.M, L.npad_h, L.groups, L.tile_h);
+    const bool allow_208 = li >= 4 && L.npad_h == 256;                 // cnv5, cnv6, cnv7: conv_igemm_h3s.h is instantiated for them
+    std::vector<LaunchH> plan = plan_layer_h3(p.M, L.npad_h, L.groups, L.tile_h, allow_208, c->ncu);
     if (fuse_pose) {      // one launch, one tile shape no taller than an image, so a tile touches <= 2 images
         const int P = Ho * Wo;
-        const int best = plan_single_tile_h3(p.M, L.npad_h, L.groups, P, L.tile_h);
+        const int best = plan_single_tile_h3(p.M, L.npad_h, L.groups, P, L.tile_h, allow_208, c->ncu);
         if (best < 0) return fail(c, DAVO_ERR_INVALID, "no tile fits the fused pose head");
         plan = {{0, p.M, best}};
         const TileShape ts = tile_shape(best);
@@ -220,7 +221,7 @@ int run_cnv1_patch(davo_ctx* c, bool fused, const void* d_img, const void* d_flo
     p.img = static_cast<const uint8_t*>(d_img); p.flow = static_cast<const float*>(d_flow);
     p.seg = static_cast<const float*>(d_seg); p.tab = c->d_tab; p.v = c->v;
     c->last_plan[0][0] = ((NB * Ho * Wo + 127) / 128) * 1000 + 99; c->last_plan[0][1] = 0;
-    const int nblk = p.ntiles < 512 ? p.ntiles : 512;          // 2 workgroups per CU, each walks its tiles
+    const int nblk = p.ntiles < 2 * c->ncu ? p.ntiles : 2 * c->ncu;   // 2 workgroups per CU, each walks its tiles
     ProfScope ps(c, "cnv1");
     HIP_TRY(c, launch_cnv1_patch(fused, p, nblk, c->stream));
     return DAVO_OK;

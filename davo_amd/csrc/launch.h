@@ -22,6 +22,8 @@ hipError_t launch_layer(int layer, int BN, const ConvParams& p, dim3 grid, hipSt
 
 // ---- launch_h3.hip: conv_igemm_h3 (f16x3) -----------------------------------------------------------
 hipError_t launch_layer_h3(int layer, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s);
+// launch_h3s.hip: conv_igemm_h3s (TILE_208x256) for layer 4..6 = cnv5, cnv6, cnv7
+hipError_t launch_layer_h3s(int layer, const ConvParamsH& p, dim3 grid, hipStream_t s);
 hipError_t launch_h3_generic(int KS, int stride, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s);
 
 // ---- launch_misc.hip: prologue, pose head, cnv1 patch kernel, direct convolution ---------------------

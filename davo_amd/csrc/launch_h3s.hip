@@ -1,0 +1,29 @@
+// launch_h3s.hip — conv_igemm_h3s (f16x3, 208-pixel x 256-channel tile) for cnv5, cnv6 and cnv7.
+#include "conv_igemm_h3s.h"
+#include "launch.h"
+
+namespace davo {
+namespace {
+
+template <int KS, int STRIDE, int LAYER>
+hipError_t launch_s(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    auto kern = conv_igemm_h3s<KS, STRIDE, LAYER>;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), TileS::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(TileS::THREADS), TileS::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_layer_h3s(int layer, const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    if (p.cb_log2 != 5) return hipErrorInvalidValue;          // whole 32-channel blocks per chunk (Cin >= 32)
+    switch (layer) {
+        case 4: return launch_s<3, 1, 5>(p, grid, s);
+        case 5: return launch_s<3, 1, 6>(p, grid, s);
+        case 6: return launch_s<3, 2, 7>(p, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace davo

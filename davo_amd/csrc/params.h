@@ -102,6 +102,16 @@ template <int WM, int WN, int TM, int TN, int NSTG = 2> struct TileH {
     static_assert(A_LOADS >= 1 && A_LOADS <= 4 && B_LOADS >= 1 && B_LOADS <= 4, "staging shape");
 };
 
+// ---- conv_igemm_h3s.h (f16x3, 208-pixel x 256-channel tile) ------------------------------
+struct TileS {
+    static constexpr int BM = 208, BN = 256, THREADS = 512, WAVES = 8;
+    static constexpr int NP = BM / 16;                 // 13 pixel groups
+    static constexpr int NC = 2;                       // 16-channel groups per wave
+    static constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128;
+    static constexpr int DUMMY = WAVES * 1024;         // where the waves without a 4th pixel-row load park theirs
+    static constexpr int LDS_BYTES = 2 * (A_SLOT + B_SLOT) + DUMMY;
+};
+
 // ---- conv_patch_h3.h (cnv1 from an LDS patch) ---------------------------------------------
 namespace cp1 {
 constexpr int KS = 7, TH = 8, TW = 16;                 // filter, output tile

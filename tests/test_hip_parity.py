@@ -721,3 +721,38 @@ def test_cli_restores_a_tf_bundle(tmp_path, c_oracle):
     infer = lambda img, flow, seg: c_oracle.forward(cfg, img, flow, seg, weights)   # noqa: E731
     want, _ = S.run_sequence(infer, S.kitti_window_loader(dump, 9, 9, 64, 96).__call__, 9, 4)
     assert got.shape == (9, 4, 4) and np.abs(got - np.array(want)).max() < 2e-4
+
+
+# ---- the 208-pixel x 256-channel tile (conv_igemm_h3s.h) -------------------------------------------------
+@pytest.mark.parametrize("B,H,W", [(1, 128, 416), (5, 128, 416), (3, 64, 96), (2, 36, 100), (1, 256, 832)])
+def test_tile_208x256_forced(c_oracle, B, H, W):
+    """cnv5, cnv6 and cnv7 forced onto the 208x256 tile (waves split the channels, weights as the MFMA A operand) at
+    shapes where its tiles are whole image rows (128x416, 256x832) and where they straddle images and end in a ragged
+    tile (64x96, 36x100): layer by layer against the 256x256-tile kernel, poses against the oracle, with the pose head
+    fused into cnv7's tiles and separate."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(B, H, W, first_window=3)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    e = _engine(cfg, H, W, B, weights, "f16x3")
+    h2, w2 = -(-H // 4), -(-W // 4)
+    for fuse_pose in (0, 1):
+        e.set_option("fuse_pose", fuse_pose)
+        e.set_option("force_tile", 4)                        # 128x128 tiles everywhere they fit
+        base = e.forward(img, flow, seg).copy()
+        l5 = e.debug_read("cnv5", (2 * B, h2, w2, 256)).copy()
+        l6 = e.debug_read("cnv6", (2 * B, h2, w2, 256)).copy()
+        e.set_option("force_tile", 6)
+        got = e.forward(img, flow, seg)
+        assert [p[1] for p in e.last_plan(4)] == [6] and [p[1] for p in e.last_plan(5)] == [6]
+        assert_pose_close(got, want, "208x256 tile, fuse_pose=%d" % fuse_pose)
+        # the same products reach every accumulator in the same order: the activations are the other kernel's, bit for bit
+        assert np.array_equal(e.debug_read("cnv5", (2 * B, h2, w2, 256)), l5)
+        assert np.array_equal(e.debug_read("cnv6", (2 * B, h2, w2, 256)), l6)
+        if not fuse_pose:
+            assert np.array_equal(got, base)
+        else:
+            assert np.abs(got - base).max() <= 1e-6 * np.abs(base).max()
+    e.set_option("force_tile", -1)
+    assert_pose_close(e.forward(img, flow, seg), want, "planner")
+    e.close()

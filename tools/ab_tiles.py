@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""A/B of launch plans in ONE process on one GPU (cdna_hip_programming.md §5.4 rule 24): per-kernel HIP-event times
+of the flagship path with the f16x3 layers forced onto one tile shape (davo_set_option "force_tile") or planned.
+
+    python tools/ab_tiles.py [--batch 32] [--tiles -1,5,6] [--rounds 3] [--steps 10] [--options k=v,...]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np                                                   # noqa: E402
+from davo_amd import Engine, synth, parse_version, FLAGSHIP_VERSION  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--height", type=int, default=128)
+    ap.add_argument("--width", type=int, default=416)
+    ap.add_argument("--tiles", default="-1,5,6")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--options", default="", help="extra davo_set_option pairs applied to every arm, k=v,k=v")
+    a = ap.parse_args()
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B, H, W = a.batch, a.height, a.width
+    e = Engine(cfg, H, W, B)
+    e.load_weights(synth.make_weights(cfg))
+    nu = min(8, B)
+    img, flow, seg = synth.make_inputs(nu, H, W)
+    reps = -(-B // nu)
+    img, flow, seg = np.tile(img, (reps, 1, 1, 1))[:B], np.tile(flow, (reps, 1, 1, 1, 1))[:B], np.tile(seg, (reps, 1, 1, 1, 1))[:B]
+    bufs = (e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48))
+    for kv in filter(None, a.options.split(",")):
+        k, v = kv.split("=")
+        e.set_option(k, int(v))
+    tiles = [int(t) for t in a.tiles.split(",")]
+    acc = {t: {} for t in tiles}
+    wall = {t: [] for t in tiles}
+    import time
+    for rnd in range(a.rounds):
+        for t in tiles:
+            e.set_option("force_tile", t)
+            for _ in range(3):
+                e.forward_device(B, *bufs)
+            e.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                e.forward_device(B, *bufs)
+            e.synchronize()
+            wall[t].append((time.perf_counter() - t0) / a.steps * 1e3)
+            e.profile(1)
+            e.profile_reset()
+            for _ in range(a.steps):
+                e.forward_device(B, *bufs)
+            for k, (n, ms) in e.profile_entries().items():
+                acc[t].setdefault(k, []).append(ms / max(n, 1))
+            e.profile(0)
+    names = []
+    for t in tiles:
+        for k in acc[t]:
+            if k not in names:
+                names.append(k)
+    print("B=%d %dx%d; ms per launch, median over %d rounds; columns = force_tile %s" % (B, H, W, a.rounds, tiles))
+    for k in names:
+        print("%-20s" % k + "".join("%10.4f" % (np.median(acc[t][k]) if k in acc[t] else float("nan")) for t in tiles))
+    print("%-20s" % "step (wall, no events)" + "".join("%10.4f" % np.median(wall[t]) for t in tiles))
+    print("%-20s" % "triplets/s" + "".join("%10.0f" % (B / np.median(wall[t]) * 1e3) for t in tiles))
+
+
+if __name__ == "__main__":
+    main()
