@@ -303,7 +303,6 @@ void conv_igemm_h3(ConvParamsH p) {
         static_assert((NI == 2 || NI == 4) && NJ >= 2 && NJ <= 8, "wave tile shape");              \
         /* DMA issue slots: groups D0 .. D0+NDG-1, DPG slots each, all in the first half of the chunk */ \
         constexpr int D0 = NJ >= 4 ? 1 : 0, NDG = NJ >= 8 ? DAVO_H3_NDG8 : 2, DPG = 8 / NDG;                  \
-        H3_DMA_SETUP(q + NST - 1, nslot)                                                           \
         const unsigned a0 = lds_u32(As + (buf_) * BMH * ROWB + (wm * TM * 32 + l16) * ROWB);       \
         const unsigned b0 = lds_u32(Bs + (buf_) * BNH * ROWB + (wn * TN * 32 + l16) * ROWB);       \
         const unsigned a_h = a0 + foff16[0], a_l = a0 + foff16[1], b_h = b0 + foff16[0], b_l = b0 + foff16[1]; \
@@ -318,6 +317,9 @@ void conv_igemm_h3(ConvParamsH p) {
         if constexpr (NI == 4) { H3_RD(a16l[NI - 2], a_l, 32 * ROWB); H3_RD(a16l[NI - 1], a_l, 48 * ROWB); } \
         H3_RD(bh[1], b_h, 16 * ROWB);                                                              \
         H3_RD(bl[1], b_l, 16 * ROWB);                                                              \
+        /* the scalar walk to the next chunk (tap, channel block, addresses) runs behind the reads it does not feed */ \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        H3_DMA_SETUP(q + NST - 1, nslot)                                                           \
         H3_GROUP(0) H3_GROUP(1) H3_GROUP(2) H3_GROUP(3) H3_GROUP(4) H3_GROUP(5) H3_GROUP(6) H3_GROUP(7)    \
         H3_DMA_ADVANCE                                                                             \
     }

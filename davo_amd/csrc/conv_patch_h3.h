@@ -25,22 +25,25 @@
 
 namespace davo {
 
-// Persistent form: the grid is 2 workgroups per CU; each stages the 28 KB of B fragments once and
-// then walks its share of the output tiles (tile t, t + gridDim.x, ...), re-filling only the 25 KB
-// input patch per tile.  With one launch-wide weight fetch instead of one per tile the kernel's
-// L2 -> LDS traffic halves (it was bound by exactly that).  Two co-resident workgroups overlap each
-// other's fill / matrix / store phases.
+// Persistent form: the grid is 3 workgroups per CU; each loads the 28 KB of B fragments into registers
+// once and then walks its share of the output tiles (tile t, t + gridDim.x, ...), re-filling only the
+// 42 KB input patch per tile.  The co-resident workgroups overlap each other's fill / matrix / store phases.
 template <bool FUSED>
-__global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchParams p) {
+__global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchParams p) {
     using namespace cp1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_p[];
     uint8_t* patch = smem_p;                   // [2][PH][2][UNITS] x 16 B
-    uint8_t* wl = smem_p + 2 * PLANE;          // [STEPS][2][64] x 16 B
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int k = wave; k < WBYTES / 1024; k += 4)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(p.w + (size_t)k * 1024 + lane * 16), (lptr_t*)(wl + k * 1024), 16, 0, 0);
+    // the B (weight) fragments of all 14 steps, hi and lo, live in registers for the whole kernel: [step][plane][lane] x 16 B.
+    // (Staged in LDS they were a third of the kernel's fragment reads and 28 KB that now admit a third workgroup per CU.)
+    half8 wreg[STEPS][2];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)(st * 2 + 0) * 64 + lane) * 16);
+        wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)(st * 2 + 1) * 64 + lane) * 16);
+    }
 
     const int r = lane & 15, kq = lane >> 4;
     const float bv = p.bias[r] * p.bias_scale;                 // C/D layout: col = lane & 15
@@ -48,7 +51,6 @@ __global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchP
     const int a_lane = (kq & 1) * ROWB + (r + (kq >> 1)) * 16;
     const uint8_t* a0 = patch + (2 * (2 * wave) * 2) * ROWB + a_lane;
     const uint8_t* a1 = patch + (2 * (2 * wave + 1) * 2) * ROWB + a_lane;
-    const uint8_t* wb = wl + lane * 16;
     const int tiles_per_img = p.tiles_x * p.tiles_y;
 
     // stage one tile's patch.  !FUSED: LDS-DMA from the packed tensor, one wave-instruction = 64 units
@@ -132,8 +134,7 @@ __global__ __launch_bounds__(cp1::THREADS, 2) void conv_patch_cnv1_h3(ConvPatchP
         for (int step = 0; step < STEPS; ++step) {
             const int ky = step >> 1, h = step & 1;
             const int aoff = ky * 2 * ROWB + h * 32;           // filter row, +2 units for taps 4..7
-            const half8 bh = lds_frag(wb + (step * 2) * 1024);
-            const half8 bl = lds_frag(wb + (step * 2 + 1) * 1024);
+            const half8 bh = wreg[step][0], bl = wreg[step][1];
             const half8 ah0 = lds_frag(a0 + aoff), al0 = lds_frag(a0 + aoff + PLANE);
             const half8 ah1 = lds_frag(a1 + aoff), al1 = lds_frag(a1 + aoff + PLANE);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc0, 0, 0, 0);

@@ -221,7 +221,7 @@ int run_cnv1_patch(davo_ctx* c, bool fused, const void* d_img, const void* d_flo
     p.img = static_cast<const uint8_t*>(d_img); p.flow = static_cast<const float*>(d_flow);
     p.seg = static_cast<const float*>(d_seg); p.tab = c->d_tab; p.v = c->v;
     c->last_plan[0][0] = ((NB * Ho * Wo + 127) / 128) * 1000 + 99; c->last_plan[0][1] = 0;
-    const int nblk = p.ntiles < 2 * c->ncu ? p.ntiles : 2 * c->ncu;   // 2 workgroups per CU, each walks its tiles
+    const int nblk = p.ntiles < 3 * c->ncu ? p.ntiles : 3 * c->ncu;   // 3 workgroups per CU, each walks its tiles
     ProfScope ps(c, "cnv1");
     HIP_TRY(c, launch_cnv1_patch(fused, p, nblk, c->stream));
     return DAVO_OK;

@@ -121,7 +121,7 @@ constexpr int ROWB = UNITS * 16;                       // 512 B
 constexpr int PLANE = PH * 2 * ROWB;                   // 21,504 B per plane (hi / lo)
 constexpr int STEPS = 2 * KS;                          // 14 MFMA steps (8 taps per filter row)
 constexpr int WBYTES = STEPS * 2 * 64 * 16;            // 28,672 B: [step][plane][lane] x 16 B
-constexpr int LDS_BYTES = 2 * PLANE + WBYTES;          // 71,680 B
+constexpr int LDS_BYTES = 2 * PLANE;                   // 43,008 B: the patch (the weight fragments live in registers)
 constexpr int THREADS = 256;
 }  // namespace cp1
 
