@@ -148,29 +148,29 @@ __global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchP
         const int tnext = t + gridDim.x;
         if (tnext < p.ntiles) issue_patch(tnext);              // the refill flies under this tile's stores
 
-        // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel), row = 4*(lane>>4) + i (pixel)
+        // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel), row = 4*(lane>>4) + i (pixel).
+        // even lanes store the hi halves of channels (n, n+1), odd lanes the lo halves of (n-1, n): one 4-byte store per value
+        const bool odd = r & 1;
+        const unsigned sel = odd ? 0x03020706u : 0x05040100u;   // perm(xn, x, sel): even = {x.lo16, xn.lo16}, odd = {xn.hi16, x.hi16}
+        const int choff = odd ? 32 + (r - 1) * 2 : r * 2;
+        const bool interior = oy0 + TH <= p.Ho && ox0 + TW <= p.Wo;        // uniform: every tile of a 128x416 / 256x832 frame
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int oy = oy0 + 2 * wave + sub;
-            if (oy >= p.Ho) continue;
+            if (!interior && oy >= p.Ho) continue;
+            uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0 + 4 * kq) * 64 + choff;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int ox = ox0 + 4 * kq + i;
                 float v = fmaxf((sub == 0 ? acc0[i] : acc1[i]) * p.out_scale, 0.f);
-                if (ox < p.Wo) vmax = fmaxf(vmax, v);
+                const bool ok = interior || ox0 + 4 * kq + i < p.Wo;
+                if (ok) vmax = fmaxf(vmax, v);
                 v = fminf(v, 65504.f);
-                if (ox < p.Wo) {
-                    // even lanes store the hi halves of channels (n, n+1), odd lanes the lo halves of (n-1, n)
-                    const _Float16 hi = (_Float16)v;
-                    const _Float16 lo = (_Float16)(v - (float)hi);
-                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
-                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
-                    const bool odd = r & 1;
-                    const unsigned word = odd ? ((xn >> 16) | (x & 0xffff0000u)) : ((x & 0xffffu) | (xn << 16));
-                    uint8_t* o = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + (odd ? 32 + (r - 1) * 2 : r * 2);
-                    *reinterpret_cast<unsigned*>(o) = word;
-                }
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                   ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                if (ok) *reinterpret_cast<unsigned*>(orow + i * 64) = __builtin_amdgcn_perm(xn, x, sel);
             }
         }
         t = tnext;
