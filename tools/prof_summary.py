@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--stats"); ap.add_argument("--fetch"); ap.add_argument("--write"); ap.add_argument("--sq")
     ap.add_argument("--out", required=True)
     ap.add_argument("--note", default="")
+    ap.add_argument("--batch", type=int, default=32, help="triplets per step of the profiled run (recorded in the traffic JSON)")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     lines = ["# rocprofv3 summary: %s" % os.path.basename(a.out), "", a.note, ""]
@@ -85,7 +86,7 @@ def main():
         for k in sorted(set(fe) | set(wr)):
             f = fe[k].get("FETCH_SIZE", []); w = wr[k].get("WRITE_SIZE", [])
             tr[k] = {"read_bytes": 2 * (sum(f) / len(f) if f else 0.0) * 1024, "write_bytes": (sum(w) / len(w) if w else 0.0) * 1024}
-        json.dump({"source": os.path.basename(a.out), "note": "per launch; FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE exact",
+        json.dump({"source": os.path.basename(a.out), "batch": a.batch, "note": "per launch; FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE exact",
                    "kernels": tr}, open(a.out + "_traffic.json", "w"), indent=1)
     open(a.out + "_summary.md", "w").write("\n".join(lines))
     print("\n".join(lines))
