@@ -442,6 +442,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     const std::string k = key;
     if (k == "fuse_pose") c->opt_fuse_pose = value != 0;
     else if (k == "fuse_pack") c->opt_fuse_pack = value != 0;
+    else if (k == "share_taps") c->opt_share_taps = value != 0;
     else if (k == "force_tile") {
         // test hook: every f16x3 layer the tile fits runs as ONE launch of that tile shape (plan.h tile ids; -1 = planner)
         if (value < -1 || value >= NUM_TILES) return fail(c, DAVO_ERR_INVALID, "force_tile must be -1..%d", NUM_TILES - 1);
@@ -593,11 +594,11 @@ int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin, c
             p.x = static_cast<const uint8_t*>(dx); p.w = static_cast<const uint8_t*>(dw);
             p.bias = static_cast<const float*>(db); p.y = static_cast<uint8_t*>(dy);
             p.zeros = static_cast<const uint8_t*>(dz);
-            p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.x_pix_bytes = (long)Cin * 4;
+            p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.x_pix_bytes = (long)Cin * 4; p.x_pix_log2 = -1;
             p.cb_log2 = L.cb_log2; p.tpc_log2 = L.tpc_log2; p.cpb = L.cpb; p.nchunks = L.nchunks_h;
             p.w_row_bytes = (long)L.nchunks_h * 128; p.y_mode = 0; p.y_ld = Cout; p.Cout = Cout;
             p.pad_t = pt; p.pad_l = pl; p.rate = rate; p.M = N * Ho * Wo; p.ntaps = k * k;
-            p.ntiles_n = L.npad_h / ts.bn; p.relu = relu; p.out_scale = 1.0f / L.wscale; p.bias_scale = L.wscale; p.range = nullptr;
+            p.Mtot = p.M; p.xs = 0; p.ntiles_n = L.npad_h / ts.bn; p.relu = relu; p.out_scale = 1.0f / L.wscale; p.bias_scale = L.wscale; p.range = nullptr;
             dim3 grid((p.M + ts.bm - 1) / ts.bm * p.ntiles_n, 1);
             const hipError_t le = launch_h3_generic(k, stride, tile, p, grid, nullptr);
             chk(le);

@@ -52,6 +52,7 @@ namespace davo {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 typedef __attribute__((address_space(3))) const uint8_t lds_u8_t;
 // 32-bit LDS address of a pointer into shared memory (operand of ds_read_*)
@@ -77,16 +78,33 @@ typedef __attribute__((address_space(3))) void lptr_t;
 // M16: use v_mfma_f32_16x16x32_f16 (K = 32 = the whole chunk per instruction) instead of 32x32x16.  Same LDS
 // bytes and matrix cycles per chunk; under matrix-dense load the chip holds a higher clock on the 16x16 shape
 // (MI355X_MICROARCH.md, DVFS give-back item 7), so the faster one is chosen by measurement.
-template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC, bool M16 = false, int NSTG = 2>
+// RATE > 0 ("XS", 3x3 stride-1 layers, 16x16x32 form): the three kx taps of a filter row share ONE staged pixel patch.
+// In flattened pixel order the taps kx = 0, 1, 2 of a dilated 3x3 filter read the same pixels shifted by RATE, so
+// per (channel block, ky) the workgroup stages BMH + 2*RATE consecutive pixels once (LDS row i = flattened pixel
+// tile_first - RATE + i of input row y + (ky-1)*RATE) and the chunk of tap kx reads its A fragments RATE*kx rows
+// further down: the pixel-operand DMA falls 2.8-2.95x (all DMA instructions and L2 -> LDS bytes by a third).
+// Where the shift leaves the image row (x < RATE for kx = 0, x >= W - RATE for kx = 2) TF's zero padding is restored
+// by AND-ing the fragment with a per-lane mask; vertical padding is the DMA's bounds test as before.  Products and
+// their order per accumulator are unchanged: results are bit-identical to RATE = 0.
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC, bool M16 = false, int NSTG = 2, int RATE = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 2)
 void conv_igemm_h3(ConvParamsH p) {
     using T = TileH<WM, WN, TM, TN, NSTG>;
+    using TX = TileX<WM, WN, TM, TN, NSTG, (RATE > 0 ? RATE : 1)>;
+    constexpr bool XS = RATE > 0;
+    static_assert(!XS || (KS == 3 && STRIDE == 1 && M16 && !SMALLC && DMA), "shared-tap staging: 3x3 stride-1 layers, 16x16x32 form");
     constexpr int BMH = T::BMH, BNH = T::BNH;
     constexpr int ROWB = DMA ? 128 : LDB;              // LDS bytes per row
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_h[];
     constexpr int NSTAGE = DMA ? T::DMA_STAGES : 2;
-    uint8_t* As = smem_h;                              // [NSTAGE][BMH][ROWB]
-    uint8_t* Bs = smem_h + NSTAGE * BMH * ROWB;        // [NSTAGE][BNH][ROWB]
+    constexpr int A_BUFS = XS ? 2 : NSTAGE, A_ROWS = XS ? TX::PR : BMH;
+    uint8_t* As = smem_h;                              // [NSTAGE][BMH][ROWB]   (XS: [2][PR][128] pixel patches)
+    uint8_t* Bs = smem_h + A_BUFS * A_ROWS * ROWB;     // [NSTAGE][BNH][ROWB]
+    uint8_t* xdummy = Bs + NSTAGE * BNH * ROWB;        // XS: 1 KB per wave, where the DMA slots past the patch's end land
+    const unsigned xzero = lds_u32(xdummy + WM * WN * 1024);    // XS: 128 zero bytes (what a tap reads outside its image row)
+    if constexpr (XS) {
+        if (threadIdx.x < 8) *reinterpret_cast<float4*>(xdummy + WM * WN * 1024 + threadIdx.x * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -139,6 +157,61 @@ void conv_igemm_h3(ConvParamsH p) {
 #pragma unroll
     for (int j = 0; j < T::B_LOADS; ++j)
         boff[j] = (unsigned)((r0 + T::ROWS_PER_PASS * j) * (int)p.w_row_bytes + u * 16);
+    // XS invariants.  Patch slot j of this thread = LDS row r0 + ROWS_PER_PASS*j = flattened pixel mtile*BMH - RATE + row.
+    constexpr int XSLOTS = XS ? TX::A_SLOTS : 1;
+    int xpix[XSLOTS];                                        // pixel index (n, y - RATE, x) of the slot at ky = 0 (only used when valid)
+    int xyv[XSLOTS];                                         // input row at ky = 0 (y - RATE), or far out of range: never valid
+    unsigned xkeep = 0xffffu;                                // bit i: row group i keeps tap kx = 0 (x >= RATE); bit 8+i: keeps kx = 2
+    const int xrow0 = wm * TM * 32 + (lane & 15);            // first fragment row of this lane inside the tile
+    const uint8_t* xgu = xg + unit_boff;
+    if constexpr (XS) {
+        const int hw = p.Hout * p.Wout;
+#pragma unroll
+        for (int j = 0; j < XSLOTS; ++j) {
+            const int row = r0 + T::ROWS_PER_PASS * j;
+            const int f = mtile * BMH - RATE + row;
+            const bool ok = row < TX::PR && f >= 0 && f < p.Mtot;
+            const int fc = ok ? f : 0;
+            const int n = fc / hw, rem = fc - n * hw;
+            const int y = rem / p.Wout, x = rem - y * p.Wout;
+            xpix[j] = (n * p.Hin + y - RATE) * p.Win + x;
+            xyv[j] = ok ? y - RATE : -(1 << 28);
+        }
+        xkeep = 0;
+#pragma unroll
+        for (int i = 0; i < 2 * TM; ++i) {
+            const int f = mtile * BMH + xrow0 + i * 16;
+            const int x = f % p.Wout;
+            if (x >= RATE) xkeep |= 1u << i;
+            if (x < p.Wout - RATE) xkeep |= 1u << (8 + i);
+        }
+    }
+    // A fragment byte offset (plane 0 = hi, 1 = lo) of tap kx from the patch base: row xrow0 + kx*RATE, unit swizzled by its row
+#define H3_XFRAG(KX_, PL_) ((unsigned)((xrow_ + (KX_) * RATE) * 128 + ((((PL_) * 4 + (lane >> 4)) ^ (((xrow_ + (KX_) * RATE) >> 1) & 7)) * 16)))
+    // A fragment of row group I_ for tap KX_: the patch row, or the zero row for the lanes the tap carries out of the image row
+#define H3_XRD(arr_, I_, base_, KX_)                                                               \
+    {                                                                                              \
+        if constexpr ((KX_) == 1) { H3_RD(arr_[I_], base_, (I_) * 16 * 128); }                     \
+        else {                                                                                     \
+            const unsigned ad_ = (xkeep >> (((KX_) == 0 ? 0 : 8) + (I_))) & 1u ? (base_) + (I_) * 16 * 128 : xzero; \
+            H3_RD(arr_[I_], ad_, 0);                                                               \
+        }                                                                                          \
+    }
+    // patch slot j_ of the super-chunk (xcblk, xky) into patch buffer abuf_; a slot past the patch's end parks in xdummy
+#define H3_XDMA_A(j_, abuf_)                                                                       \
+    {                                                                                              \
+        if constexpr ((j_) < XSLOTS) {                                                             \
+            const int iy = xyv[j_] + xdy;                                                          \
+            const bool ok = (unsigned)iy < (unsigned)p.Hin;                                        \
+            uint8_t* dst_ = (8 * wave_u + (j_) * T::ROWS_PER_PASS) < TX::PR                        \
+                                ? As + (abuf_) * TX::PR * 128 + ((j_) * T::ROWS_PER_PASS + 8 * wave_u) * 128 \
+                                : xdummy + wave_u * 1024;                                          \
+            const uint8_t* src_ = xgu + (((long)(xpix[j_] + xdp_)) << p.x_pix_log2) + xcoff;       \
+            __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? src_ : p.zeros), (lptr_t*)dst_, 16, 0, 0); \
+        } else {                                                                                   \
+            __builtin_amdgcn_global_load_lds((gptr_t*)p.zeros, (lptr_t*)(xdummy + wave_u * 1024), 16, 0, 0); \
+        }                                                                                          \
+    }
 #define H3_DMA_A(j_)                                                                               \
     if constexpr (T::A_LOADS > j_) {                                                               \
         const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
@@ -323,6 +396,81 @@ void conv_igemm_h3(ConvParamsH p) {
         H3_GROUP(0) H3_GROUP(1) H3_GROUP(2) H3_GROUP(3) H3_GROUP(4) H3_GROUP(5) H3_GROUP(6) H3_GROUP(7)    \
         H3_DMA_ADVANCE                                                                             \
     }
+    // ---- XS: the same hand-scheduled chunk with the A fragments read RATE*kx rows down the shared patch -------------
+    // DMA slot s of a chunk: the chunk's share of the next patch first, then the next weight chunk
+#define H3_XSLOT(s_, KX_, nabuf_)                                                                  \
+    {                                                                                              \
+        if constexpr ((s_) < TX::APC) { H3_XDMA_A(KX_ * TX::APC + (s_), nabuf_) }                  \
+        else if constexpr ((s_) - TX::APC == 0) { H3_DMA_B(0) }                                    \
+        else if constexpr ((s_) - TX::APC == 1) { H3_DMA_B(1) }                                    \
+        else if constexpr ((s_) - TX::APC == 2) { H3_DMA_B(2) }                                    \
+        else if constexpr ((s_) - TX::APC == 3) { H3_DMA_B(3) }                                    \
+    }
+#define H3_XSLOTS_OF_GROUP(g_, KX_, nabuf_)                                                                     \
+    { H3_XSLOT((g_) * DPGX, KX_, nabuf_) H3_XSLOT((g_) * DPGX + 1, KX_, nabuf_) H3_XSLOT((g_) * DPGX + 2, KX_, nabuf_) }
+#define H3_GROUPX(J_, KX_, nabuf_)                                                                              \
+    if constexpr ((J_) < NJ) {                                                                     \
+        if constexpr ((J_) + 2 < NJ) {                                                             \
+            H3_RD(bh[(J_) + 2 < NJ ? (J_) + 2 : 0], b_h, ((J_) + 2) * 16 * ROWB);                  \
+            H3_RD(bl[(J_) + 2 < NJ ? (J_) + 2 : 0], b_l, ((J_) + 2) * 16 * ROWB);                  \
+        }                                                                                          \
+        constexpr int after = 2 * ((J_) + 1 < NJ) + 2 * ((J_) + 2 < NJ);     /* B reads newer than group J_'s */ \
+        if constexpr ((J_) == 0) {                                                                 \
+            H3_WAIT_A(1 + NI + after, a16h)                                                        \
+            H3_WAIT_B(1 + NI + after, bh[0]);                                                      \
+            H3_MFMA_ROW(a16h, bh[0], 0)                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            H3_WAIT_B(NI + after, bl[0]);                                                          \
+            H3_MFMA_ROW(a16h, bl[0], 0)                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            H3_WAIT_A(after, a16l)                                                                 \
+            H3_MFMA_ROW(a16l, bh[0], 0)                                                            \
+            if constexpr (D0 == 0) H3_XSLOTS_OF_GROUP(0, KX_, nabuf_)                                         \
+        } else {                                                                                   \
+            H3_WAIT_B(after, bh[J_]);                                                              \
+            H3_WAIT_B(after, bl[J_]);                                                              \
+            constexpr bool dma_here = (J_) >= D0 && (J_) < D0 + 2;                                 \
+            if constexpr (dma_here) H3_XSLOTS_OF_GROUP((J_) - D0, KX_, nabuf_)                                \
+            H3_MFMA_ROW(a16h, bh[J_], J_)                                                          \
+            H3_MFMA_ROW(a16h, bl[J_], J_)                                                          \
+            H3_MFMA_ROW(a16l, bh[J_], J_)                                                          \
+            if constexpr (dma_here) H3_ILV(4, (3 * NI) / DPGX)                                     \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+    // chunk of tap KX_ (compile time: the fragment addresses of the three taps live in registers), weights in ring slot
+    // bslot_, patch buffer abuf_; its DMA slots fetch the next weight chunk into nslot and patch slots of the next
+    // super-chunk into nabuf_
+#define H3_CHUNK16X(KX_, bslot_, abuf_, nabuf_)                                                    \
+    {                                                                                              \
+        constexpr int NI = 2 * TM, NJ = 2 * TN;                                                    \
+        constexpr int D0 = NJ >= 4 ? 1 : 0;                                                        \
+        constexpr int NSL = TX::APC + T::B_LOADS, DPGX = (NSL + 1) / 2;                            \
+        static_assert(DPGX <= 3 && NSL <= 6, "DMA slots per group");                               \
+        /* per-chunk copies behind an empty asm: without them the compiler computes the three taps' fragment offsets and   \
+           the five patch slots' 64-bit addresses once per super-chunk and keeps them live (16 registers: it spilled) */   \
+        int xrow_ = xrow0, xdp_ = xdpix;                                                           \
+        asm volatile("" : "+v"(xrow_), "+s"(xdp_));                                                \
+        const unsigned pb_ = lds_u32(As + (abuf_) * TX::PR * 128);                                 \
+        const unsigned b0 = lds_u32(Bs + (bslot_) * BNH * ROWB + (wn * TN * 32 + l16) * ROWB);     \
+        const unsigned a_h = pb_ + H3_XFRAG(KX_, 0), a_l = pb_ + H3_XFRAG(KX_, 1), b_h = b0 + foff16[0], b_l = b0 + foff16[1]; \
+        half8 bh[NJ], bl[NJ];                                                                      \
+        /* where a shifted tap leaves the image row (kx = 0: x < RATE, kx = 2: x >= W - RATE) TF pads with zeros: those   \
+           lanes read the zero row instead of the patch - no arithmetic on the fragments, no register held for it */      \
+        H3_XRD(a16h, 0, a_h, KX_) H3_XRD(a16h, 1, a_h, KX_)                                        \
+        if constexpr (NI == 4) { H3_XRD(a16h, NI - 2, a_h, KX_) H3_XRD(a16h, NI - 1, a_h, KX_) }   \
+        H3_RD(bh[0], b_h, 0);                                                                      \
+        H3_RD(bl[0], b_l, 0);                                                                      \
+        H3_XRD(a16l, 0, a_l, KX_) H3_XRD(a16l, 1, a_l, KX_)                                        \
+        if constexpr (NI == 4) { H3_XRD(a16l, NI - 2, a_l, KX_) H3_XRD(a16l, NI - 1, a_l, KX_) }   \
+        H3_RD(bh[1], b_h, 16 * ROWB);                                                              \
+        H3_RD(bl[1], b_l, 16 * ROWB);                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        uint8_t* b_ = Bs + nslot * BNH * 128;                                                      \
+        const uint8_t* wq = wg + (long)(q + NST - 1 < p.nchunks ? q + NST - 1 : p.nchunks - 1) * 128; \
+        H3_GROUPX(0, KX_, nabuf_) H3_GROUPX(1, KX_, nabuf_) H3_GROUPX(2, KX_, nabuf_) H3_GROUPX(3, KX_, nabuf_)    \
+        H3_GROUPX(4, KX_, nabuf_) H3_GROUPX(5, KX_, nabuf_) H3_GROUPX(6, KX_, nabuf_) H3_GROUPX(7, KX_, nabuf_)    \
+    }
 #define H3_STEP(buf_, s_)                                                                          \
     {                                                                                              \
         if constexpr (M16) H3_STEP16(buf_, s_) else H3_STEP32(buf_, s_)                            \
@@ -386,6 +534,55 @@ void conv_igemm_h3(ConvParamsH p) {
         constexpr int KEEP = (NST - 2) * NDMA;                // instructions allowed to stay in flight
         constexpr int WAIT_KEEP = (KEEP & 15) | (7 << 4) | (15 << 8) | ((KEEP >> 4) << 14);   // vmcnt(KEEP) only
         constexpr int WAIT_ALL = (7 << 4) | (15 << 8);                                        // vmcnt(0) only
+        if constexpr (XS) {
+            // Super-chunk sc = (channel block, ky) = three chunks kx = 0, 1, 2 on ONE pixel patch (buffer sc & 1); the next
+            // super-chunk's patch arrives in the other buffer, its DMA slots spread over the three chunks, and every chunk
+            // fetches the next weight chunk into the ring as before.  Patch slots past the super-chunks (and weight chunks
+            // past the end) are issued all the same, reading the zero line: the per-chunk instruction count stays constant
+            // for the counted wait, and no branch cuts the interleaved code.
+            const int nsc = p.nchunks / 3;
+            int xcblk = 0, xky = 0;
+            {
+                const int xdy = 0, xdp_ = 0, xcoff = 0;
+                H3_XDMA_A(0, 0) H3_XDMA_A(1, 0) H3_XDMA_A(2, 0)
+                if constexpr (XSLOTS > 3) H3_XDMA_A(3, 0)
+                if constexpr (XSLOTS > 4) H3_XDMA_A(4, 0)
+                static_assert(XSLOTS <= 5, "patch slots per thread");
+                for (int c0 = 0; c0 < NST - 1 && c0 < p.nchunks; ++c0) {
+                    uint8_t* b_ = Bs + c0 * BNH * 128;
+                    const uint8_t* wq = wg + (long)c0 * 128;
+                    H3_DMA_B(0) H3_DMA_B(1) H3_DMA_B(2) H3_DMA_B(3)
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the zero row's ds_write
+            __builtin_amdgcn_s_barrier();
+            constexpr int XKEEP = (NST - 2) * (TX::APC + T::B_LOADS);
+            constexpr int XWAIT_KEEP = (XKEEP & 15) | (7 << 4) | (15 << 8) | ((XKEEP >> 4) << 14);
+            int slot = 0, q = 0;
+#define H3_XSTEP(KX_)                                                                              \
+            {                                                                                      \
+                const int nslot = slot == 0 ? NST - 1 : slot - 1;                                  \
+                H3_CHUNK16X(KX_, slot, abuf, nabuf)                                                \
+                if (q + 1 < p.nchunks) {                                                           \
+                    /* the patch of the next super-chunk must have landed when its first chunk starts: drain after kx = 2 */ \
+                    if (NST >= 3 && KX_ != 2) __builtin_amdgcn_s_waitcnt(XWAIT_KEEP);              \
+                    else __builtin_amdgcn_s_waitcnt(WAIT_ALL);                                     \
+                    __builtin_amdgcn_s_barrier();                                                  \
+                }                                                                                  \
+                slot = slot == NST - 1 ? 0 : slot + 1;                                             \
+                ++q;                                                                               \
+            }
+            for (int sc = 0; sc < nsc; ++sc) {
+                if (++xky == 3) { xky = 0; ++xcblk; }                 // the super-chunk whose patch this one fetches
+                const int xdy = sc + 1 < nsc ? xky * RATE : -(1 << 28);
+                const int xdpix = xky * RATE * p.Win, xcoff = xcblk * 128;
+                const int abuf = sc & 1, nabuf = abuf ^ 1;
+                H3_XSTEP(0) H3_XSTEP(1) H3_XSTEP(2)
+            }
+#undef H3_XSTEP
+            __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+        } else {
         H3_DMA_CHUNK(0, 0)
         if constexpr (NST >= 3) {
             if (p.nchunks >= NST - 1) {
@@ -427,6 +624,7 @@ void conv_igemm_h3(ConvParamsH p) {
             slot = slot == NST - 1 ? 0 : slot + 1;
         }
         if constexpr (M16) __builtin_amdgcn_s_waitcnt(WAIT_ALL);   // the last chunk's filler DMA must land before LDS is reused
+        }
     }
 
     if (H3_DBG(32)) return;                                       // measurement only: no epilogue
@@ -591,6 +789,13 @@ void conv_igemm_h3(ConvParamsH p) {
 
 #undef H3_DBG
 #undef H3_DMA_A
+#undef H3_XDMA_A
+#undef H3_XFRAG
+#undef H3_XRD
+#undef H3_XSLOT
+#undef H3_XSLOTS_OF_GROUP
+#undef H3_GROUPX
+#undef H3_CHUNK16X
 #undef H3_DMA_B
 #undef H3_DMA_CHUNK
 #undef H3_DMA_SLOT

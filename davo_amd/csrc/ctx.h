@@ -73,6 +73,7 @@ struct davo_ctx {
     bool user_stream = false;
     bool opt_fuse_pose = true;                 // f16x3: pose head fused into cnv7's epilogue (davo_set_option)
     bool opt_fuse_pack = false;                // f16x3: mask+pack fused into cnv1's patch fill
+    bool opt_share_taps = true;                // f16x3: cnv3..cnv6 stage one pixel patch per filter row for its three taps
     float* d_pose_tiles = nullptr;             // per-tile partial sums of the fused pose head
     size_t pose_tiles_floats = 0;
     bool cnv7_valid = true;

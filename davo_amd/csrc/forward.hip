@@ -143,12 +143,13 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
     p.x = static_cast<const uint8_t*>(x); p.w = L.d_wh; p.bias = L.d_bh; p.y = static_cast<uint8_t*>(y);
     p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
     p.Hin = Hin; p.Win = Win; p.Hout = Ho; p.Wout = Wo;
-    p.x_pix_bytes = (long)x_ch * 4; p.x_boff = 0;
+    p.x_pix_bytes = (long)x_ch * 4; p.x_boff = 0; p.x_pix_log2 = ilog2_exact(x_ch * 4);
     p.cb_log2 = L.cb_log2; p.tpc_log2 = L.tpc_log2; p.cpb = L.cpb; p.nchunks = L.nchunks_h;
     p.w_row_bytes = (long)L.nchunks_h * 128;
     p.y_mode = y_f32 ? 0 : 1; p.y_ld = y_ld; p.y_coff = 0; p.Cout = L.cout;
     p.pad_t = pt; p.pad_l = pl; p.rate = L.rate;
     p.M = NB * Ho * Wo; p.ntaps = L.KS * L.KS; p.mtile0 = 0; p.relu = 1;
+    p.Mtot = p.M; p.xs = c->opt_share_taps ? 1 : 0;
     {   // stored activations carry 2^act_shift (exact); cnv7 feeds the float32 pose head unscaled
         const int sin = li == 0 ? 0 : c->act_shift[li - 1], sout = li == 6 ? 0 : c->act_shift[li];
         p.out_scale = ldexpf(1.0f / L.wscale, sout - sin);

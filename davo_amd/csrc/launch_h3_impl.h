@@ -21,10 +21,29 @@ inline bool use_m16() {
     return v != 0;
 }
 
+// dilation rate of the PoseNN layer behind a LAYER tag (nets/posenn.py:213-215,238): cnv3 2, cnv4 4, cnv5 8, cnv6 2;
+// 0 = the layer has no shared-tap instantiation (stride 2, 5x5 / 7x7, generic shapes)
+constexpr int layer_rate(int layer) { return layer == 3 ? 2 : layer == 4 ? 4 : layer == 5 ? 8 : layer == 6 ? 2 : 0; }
+
 // All f16x3 launches are LDS-DMA staged.  SMALLC (Cin < 32) is a property of the layer.
 template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool SMALLC, bool M16, int NSTG = 2>
 hipError_t launch_m(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     using T = TileH<WM, WN, TM, TN, NSTG>;
+    // measured per tile shape (gpurun_out/ab_r02v.log, B=32 and B=128): -3 % on the 256x256 tile (cnv5, cnv6 main launches),
+    // +15 % on 256x64 (cnv3), +18 % on the 3-slot 128x128 remainder tile, level on 128x128 (cnv4): 256x256 only
+    if constexpr (M16 && !SMALLC && KS == 3 && STRIDE == 1 && layer_rate(LAYER) > 0 && WM == 4 && WN == 2 && TM == 2 && TN == 4) {
+        // shared-tap staging (conv_igemm_h3.h, RATE > 0): one pixel patch per filter row serves its three taps
+        constexpr int RATE = layer_rate(LAYER);
+        if (p.xs && p.rate == RATE && p.pad_l == RATE && p.pad_t == RATE && p.Hin == p.Hout && p.Win == p.Wout &&
+            p.nchunks % 3 == 0 && p.Wout > 2 * RATE && p.x_pix_log2 >= 7) {
+            using TX = TileX<WM, WN, TM, TN, NSTG, RATE>;
+            auto kx = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, true, SMALLC, M16, NSTG, RATE>;
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kx), TX::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kx, grid, dim3(T::THREADS), TX::LDS_BYTES, s, p);
+            return hipGetLastError();
+        }
+    }
     auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, true, SMALLC, M16, NSTG>;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES_DMA);
     if (e != hipSuccess) return e;

@@ -59,6 +59,7 @@ struct ConvParamsH {
     const uint8_t* zeros;   // >= 16 zero bytes: what a padded (out-of-image) tap reads
     int Hin, Win, Hout, Wout;
     long x_pix_bytes;       // bytes per input pixel (all channels of the tensor x 4)
+    int x_pix_log2;         // log2 of it when it is a power of two (shared-tap staging needs one), else -1
     int x_boff;             // byte offset inside a pixel of the first channel block used
     int cb_log2;            // CB = channels per block = min(Cin, 32)
     int tpc_log2;           // taps per chunk = 32 / CB
@@ -68,6 +69,9 @@ struct ConvParamsH {
     int y_mode, y_ld, y_coff, Cout;
     int pad_t, pad_l, rate;
     int M, ntaps, ntiles_n, mtile0, relu;
+    int Mtot;               // output rows of the whole layer (M is this launch's upper row bound): shared-tap staging reads the
+                            // pixels RATE before and after a tile, which may belong to the layer's other launch
+    int xs;                 // host: issue the shared-tap instantiation (conv_igemm_h3 RATE > 0) where the layer has one
     int g_x_boff, g_y_coff;
     long g_w, g_bias;
     float out_scale;        // 2^(shift_out - shift_in) / (power of two the layer's weights were multiplied by)
@@ -100,6 +104,16 @@ template <int WM, int WN, int TM, int TN, int NSTG = 2> struct TileH {
     static constexpr int DMA_STAGES = DAVO_H3_STAGES == 2 ? NSTG : DAVO_H3_STAGES;
     static constexpr int LDS_BYTES_DMA = DMA_STAGES * (BMH + BNH) * 128;   // LDS-DMA ring: linear rows, XOR-swizzled units
     static_assert(A_LOADS >= 1 && A_LOADS <= 4 && B_LOADS >= 1 && B_LOADS <= 4, "staging shape");
+};
+
+// conv_igemm_h3 with RATE > 0: the three kx taps of a filter row read one staged patch of BMH + 2*RATE pixels
+template <int WM, int WN, int TM, int TN, int NSTG, int RATE> struct TileX {
+    using T = TileH<WM, WN, TM, TN, NSTG>;
+    static constexpr int PR = (T::BMH + 2 * RATE + 7) / 8 * 8;           // patch rows (a DMA wave-instruction = 8 rows)
+    static constexpr int NWV = WM * WN;
+    static constexpr int A_SLOTS = (PR / 8 + NWV - 1) / NWV;             // patch DMA instructions per thread per super-chunk
+    static constexpr int APC = (A_SLOTS + 2) / 3;                        // ... issued per chunk
+    static constexpr int LDS_BYTES = 2 * PR * 128 + T::DMA_STAGES * T::BNH * 128 + NWV * 1024 + 128;   // + parking + zero row
 };
 
 // ---- conv_igemm_h3s.h (f16x3, 208-pixel x 256-channel tile) ------------------------------

@@ -756,3 +756,31 @@ def test_tile_208x256_forced(c_oracle, B, H, W):
     e.set_option("force_tile", -1)
     assert_pose_close(e.forward(img, flow, seg), want, "planner")
     e.close()
+
+
+# ---- shared-tap staging (conv_igemm_h3 RATE > 0) ---------------------------------------------------------
+@pytest.mark.parametrize("B,H,W", [(1, 128, 416), (5, 128, 416), (3, 64, 96), (2, 36, 100), (2, 20, 48), (1, 256, 832)])
+def test_shared_tap_staging_is_bit_identical(c_oracle, B, H, W):
+    """cnv3..cnv6 stage ONE pixel patch per filter row for its three kx taps (a third fewer DMA instructions and L2->LDS
+    bytes); lanes whose shifted tap leaves the image row read a zero row.  Same products, same order: every activation
+    and the poses are bit-identical to the per-tap staging, at whole-row tiles (128x416, 256x832), at tiles straddling
+    image rows and images (64x96, 36x100), and where the map is narrower than the dilation (20x48: falls back per layer)."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(B, H, W, first_window=11)
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, H, W, B, weights, "f16x3")
+    e.set_option("fuse_pose", 0)
+    h2, w2 = -(-H // 4), -(-W // 4)
+    shapes = {"cnv3": 64, "cnv4": 128, "cnv5": 256, "cnv6": 256}
+    for tile in (-1, 4, 5):                                 # planner (main + remainder launches), 128x128, 256x256
+        e.set_option("force_tile", tile)
+        e.set_option("share_taps", 0)
+        base = e.forward(img, flow, seg).copy()
+        acts = {k: e.debug_read(k, (2 * B, h2, w2, c)).copy() for k, c in shapes.items()}
+        e.set_option("share_taps", 1)
+        got = e.forward(img, flow, seg)
+        for k, c in shapes.items():
+            assert np.array_equal(e.debug_read(k, (2 * B, h2, w2, c)), acts[k]), (k, tile)
+        assert np.array_equal(got, base)
+    assert_pose_close(got, c_oracle.forward(cfg, img, flow, seg, weights), "shared taps")
+    e.close()

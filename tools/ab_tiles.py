@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--options", default="", help="extra davo_set_option pairs applied to every arm, k=v,k=v")
+    ap.add_argument("--inflight", type=int, default=1, help="batches in flight (consecutive calls rotate through that many streams)")
     a = ap.parse_args()
     cfg = parse_version(FLAGSHIP_VERSION)
     B, H, W = a.batch, a.height, a.width
@@ -32,7 +33,9 @@ def main():
     img, flow, seg = synth.make_inputs(nu, H, W)
     reps = -(-B // nu)
     img, flow, seg = np.tile(img, (reps, 1, 1, 1))[:B], np.tile(flow, (reps, 1, 1, 1, 1))[:B], np.tile(seg, (reps, 1, 1, 1, 1))[:B]
-    bufs = (e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48))
+    sets = [(e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48))
+            for _ in range(a.inflight)]
+    e.set_inflight(a.inflight)
     for kv in filter(None, a.options.split(",")):
         k, v = kv.split("=")
         e.set_option(k, int(v))
@@ -43,18 +46,18 @@ def main():
     for rnd in range(a.rounds):
         for t in tiles:
             e.set_option("force_tile", t)
-            for _ in range(3):
-                e.forward_device(B, *bufs)
+            for i in range(3 * a.inflight):
+                e.forward_device(B, *sets[i % a.inflight])
             e.synchronize()
             t0 = time.perf_counter()
-            for _ in range(a.steps):
-                e.forward_device(B, *bufs)
+            for i in range(a.steps):
+                e.forward_device(B, *sets[i % a.inflight])
             e.synchronize()
             wall[t].append((time.perf_counter() - t0) / a.steps * 1e3)
             e.profile(1)
             e.profile_reset()
-            for _ in range(a.steps):
-                e.forward_device(B, *bufs)
+            for i in range(a.steps):
+                e.forward_device(B, *sets[i % a.inflight])
             for k, (n, ms) in e.profile_entries().items():
                 acc[t].setdefault(k, []).append(ms / max(n, 1))
             e.profile(0)

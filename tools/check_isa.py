@@ -28,7 +28,7 @@ def check(path):
         m = re.match(r"^(_ZN4davo13conv_igemm_h3\w+):", line)
         if m:
             name, in_chunk, saw_barrier = m.group(1), False, False
-            m16 = re.search(r"Lb1ELb[01]ELb1ELi\dEEEvNS", name) is not None       # <..., DMA=true, SMALLC, M16=true, NSTG>
+            m16 = re.search(r"Lb1ELb[01]ELb1ELi\dELi\dEEEvNS", name) is not None   # <..., DMA=true, SMALLC, M16=true, NSTG, RATE>
             if not m16:
                 name = None
             else:
