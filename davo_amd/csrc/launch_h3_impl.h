@@ -30,8 +30,8 @@ template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool SM
 hipError_t launch_m(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     using T = TileH<WM, WN, TM, TN, NSTG>;
     // measured per tile shape (gpurun_out/ab_r02v.log, B=32 and B=128): -3 % on the 256x256 tile (cnv5, cnv6 main launches),
-    // +15 % on 256x64 (cnv3), +18 % on the 3-slot 128x128 remainder tile, level on 128x128 (cnv4): 256x256 only
-    if constexpr (M16 && !SMALLC && KS == 3 && STRIDE == 1 && layer_rate(LAYER) > 0 && WM == 4 && WN == 2 && TM == 2 && TN == 4) {
+    // -6 % on 256x128 (ab_r02w.log), +15 % on 256x64 (cnv3), +18 % on the 3-slot 128x128 remainder tile, level on 128x128 (cnv4)
+    if constexpr (M16 && !SMALLC && KS == 3 && STRIDE == 1 && layer_rate(LAYER) > 0 && WM == 4 && WN == 2 && TM == 2 && (TN == 4 || TN == 2)) {
         // shared-tap staging (conv_igemm_h3.h, RATE > 0): one pixel patch per filter row serves its three taps
         constexpr int RATE = layer_rate(LAYER);
         if (p.xs && p.rate == RATE && p.pad_l == RATE && p.pad_t == RATE && p.Hin == p.Hout && p.Win == p.Wout &&
