@@ -31,7 +31,7 @@ hipError_t launch_se_squeeze(const float* d_flow, int B, int HW, const Variant& 
 
 hipError_t launch_se_excite(const float* d_partial, int B, int HW, const Variant& v, const float* w1, const float* b1,
                             const float* w2, const float* b2, const float* wstatic, float* d_tab, hipStream_t s) {
-    hipLaunchKernelGGL(se_excite, dim3(B), dim3(64), 0, s, d_partial, HW, v, w1, b1, w2, b2, wstatic, d_tab);
+    hipLaunchKernelGGL(se_excite, dim3(B, 3), dim3(64), 0, s, d_partial, HW, v, w1, b1, w2, b2, wstatic, d_tab);
     return hipGetLastError();
 }
 

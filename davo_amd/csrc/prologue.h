@@ -58,19 +58,22 @@ __global__ __launch_bounds__(256) void se_squeeze_partial(const float* __restric
 }
 
 // SE pass 2 + excitation: tab[b][frame][19] for frame = (tgt, src0, src1).
-// One 64-thread block per triplet; lanes 1,2 run the tiny MLP for src0, src1.
+// One 64-lane wave per (triplet, frame): lanes 0..31 fetch the squeeze partials (fixed butterfly: bitwise reproducible),
+// every lane evaluates the 8 bottleneck units, lane c < 19 the class c of the recovery layer — the three dependent
+// steps of the MLP cost three memory round trips instead of the ~200 a single lane needed.
 __global__ __launch_bounds__(64) void se_excite(const float* __restrict__ partial, int HW, Variant v,
                                                 const float* __restrict__ w1, const float* __restrict__ b1,
                                                 const float* __restrict__ w2, const float* __restrict__ b2,
                                                 const float* __restrict__ wstatic,
                                                 float* __restrict__ tab) {
-    const int b = blockIdx.x, frame = threadIdx.x;
-    if (frame >= 3) return;
+    const int b = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x;
     float* t = tab + ((size_t)b * 3 + frame) * NCLS;
     if (v.att_source == 1 && frame >= 1) {
         const float* pp = partial + ((size_t)b * 2 + (frame - 1)) * SQ_CHUNKS * 2;
-        float sx = 0.f, sy = 0.f;
-        for (int i = 0; i < SQ_CHUNKS; ++i) { sx += pp[2 * i]; sy += pp[2 * i + 1]; }
+        static_assert(SQ_CHUNKS == 32, "one partial pair per lane of the lower half-wave");
+        float sx = lane < SQ_CHUNKS ? pp[2 * lane] : 0.f, sy = lane < SQ_CHUNKS ? pp[2 * lane + 1] : 0.f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
         const float inv = 1.0f / (float)HW;
         sx *= inv; sy *= inv;                                  // tf.reduce_mean(axis=[1,2])
         float e[8];
@@ -79,16 +82,15 @@ __global__ __launch_bounds__(64) void se_excite(const float* __restrict__ partia
             float z = sx * w1[j] + sy * w1[8 + j] + b1[j];     // dense [2,8]
             e[j] = v.se_act == 1 ? tanhf(z) : v.se_act == 2 ? (z > 0.f ? z : 0.2f * z) : fmaxf(z, 0.f);
         }
-        for (int c = 0; c < NCLS; ++c) {
-            float z = b2[c];
+        if (lane < NCLS) {
+            float z = b2[lane];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) z += e[j] * w2[j * NCLS + c];   // dense [8,19]
-            t[c] = 1.0f / (1.0f + expf(-z));
+            for (int j = 0; j < 8; ++j) z += e[j] * w2[j * NCLS + lane];   // dense [8,19]
+            t[lane] = 1.0f / (1.0f + expf(-z));
         }
-    } else if ((v.att_source == 2 && frame >= 1) || v.att_source == 3) {
-        for (int c = 0; c < NCLS; ++c) t[c] = 1.0f / (1.0f + expf(-wstatic[c]));
-    } else {
-        for (int c = 0; c < NCLS; ++c) t[c] = 1.0f;            // davo.py:1408-1412 / 1385-1389
+    } else if (lane < NCLS) {
+        if ((v.att_source == 2 && frame >= 1) || v.att_source == 3) t[lane] = 1.0f / (1.0f + expf(-wstatic[lane]));
+        else t[lane] = 1.0f;                                   // davo.py:1408-1412 / 1385-1389
     }
 }
 
