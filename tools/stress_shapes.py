@@ -42,7 +42,13 @@ def main():
         e = Engine(cfg, H, W, B)
         e.load_weights(weights)
         e.set_precision("f16x3")
+        # every other case also walks the option space: a forced tile shape (incl. the 208x256 kernel) and the per-tap staging
+        if case % 2:
+            e.set_option("force_tile", int(rng.choice([-1, 2, 3, 4, 5, 6])))
+            e.set_option("share_taps", int(rng.randint(2)))
         a = e.forward(img, flow, seg).copy()
+        e.set_option("force_tile", -1)
+        e.set_option("share_taps", 1)
         a2 = e.forward(img[:max(1, B // 2)], flow[:max(1, B // 2)], seg[:max(1, B // 2)]).copy()
         e.set_precision("f32")
         b = e.forward(img, flow, seg).copy()
