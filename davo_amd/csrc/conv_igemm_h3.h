@@ -111,6 +111,15 @@ void conv_igemm_h3(ConvParamsH p) {
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wid / WN, wn = wid % WN;
 
+#ifdef DAVO_TUNING
+    // tuning build only (8192): the workgroups that fill a CU's 2nd, 3rd ... slot in the first round start late by
+    // slot x dbg[23:16] x ~4 us (dbg[27:24] = slots per CU), so that co-resident workgroups run out of phase
+    if (H3_DBG(8192)) {
+        const int slot_i = blockIdx.x / 256, nslot_ = (p.dbg >> 24) & 0xf;
+        if (slot_i >= 1 && slot_i < nslot_ && blockIdx.y == 0)
+            for (int i = 0; i < slot_i * ((p.dbg >> 16) & 0xff); ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int ntile = tile % p.ntiles_n, mtile = p.mtile0 + tile / p.ntiles_n;
     const int grp = blockIdx.y;

@@ -47,6 +47,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, q16 = lane >> 4;
 
+#ifdef DAVO_TUNING
+    // tuning build only: de-phase the rounds of a launch - half of the first round's workgroups (1024: by XCD parity,
+    // 2048: half of every XCD's CUs) start dbg[23:16] x ~4 us late, so that the halves' store bursts no longer coincide
+    if (HS_DBG(1024 | 2048) && blockIdx.x < 256 && blockIdx.y == 0 &&
+        (HS_DBG(1024) ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & 1))) {
+        const int nsl = (p.dbg >> 16) & 0xff;
+        for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int ntile = tile % p.ntiles_n, mtile = p.mtile0 + tile / p.ntiles_n;
     const int grp = blockIdx.y;
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
             iy0[j] = oy * STRIDE - p.pad_t;
             ix0[j] = ox * STRIDE - p.pad_l;
-            pix0 = n * p.Hin * p.Win;
+            pix0 = HS_DBG(4096) ? 0 : n * p.Hin * p.Win;     // 4096, tuning build only: every tile reads image 0 (input stays in L2)
         } else {
             iy0[j] = -(1 << 28);                       // every tap out of bounds -> the zero line
             ix0[j] = 0;

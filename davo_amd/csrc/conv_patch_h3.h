@@ -183,4 +183,127 @@ __global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchP
     }
 }
 
+// ---- cnv2 (5x5, stride 2, 16 -> 32 channels) from an LDS patch ------------------------------------
+// As an implicit GEMM cnv2 was bound by its gather (13 chunks x 128-byte rows assembled from 16-byte pieces of two taps:
+// 0.043 ms at B=32, 0.028 with the loads pointed at one line, 0.003 of it matrix time).  Here a workgroup stages the
+// 19 x 20-pixel input patch of an 8 x 8 output tile once (24 KB, double-buffered: the next tile's patch flies under this
+// tile's matrix phase and stores) and builds the A fragments of v_mfma_f32_16x16x32_f16 straight from it: K = 32 = 2 taps
+// x 16 channels, so a lane's fragment is 8 channels (one 16-byte unit) of one tap of one pixel.
+// Patch layout: four regions [plane hi|lo][channel half], each [patch row][column parity][10 units] x 16 B.  A pixel group
+// is 2 output rows x 8 columns: lanes 0-7 read 8 consecutive units, lanes 8-15 the same units two patch rows (640 B = 128
+// mod 256) further on, and region bases are multiples of 256 B, so the 16 lanes of every ds_read_b128 service group
+// cover the 64 banks once whatever mix of k-quarters the group holds.  Taps are enumerated 6 per filter row (kx = 5 is a
+// zero-weight dummy): 15 steps.  Wave w owns output channels 16 (w & 1) .. +15 (its 30 weight fragments live in registers
+// for the whole kernel) and the pixel groups 2 (w >> 1), +1.  Persistent: each workgroup walks tiles t, t + grid, ...
+__global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchParams p) {
+    using namespace cp2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_p2[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ng = wave & 1, g0 = 2 * (wave >> 1);
+    half8 wreg[STEPS][2];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 0) * 64 + lane) * 16);
+        wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 1) * 64 + lane) * 16);
+    }
+    const int r = lane & 15, kq = lane >> 4;
+    const float bv = p.bias[16 * ng + r] * p.bias_scale;       // C/D layout: col = lane & 15 = channel
+    // A fragment of group g, step (ky, h), plane pl:  region (pl, kq & 1), patch row 2 (2 g + (r >> 3)) + ky, parity kq >> 1
+    // (kx = 2 h + (kq >> 1)), unit (r & 7) + h
+    const int a_lane = (kq & 1) * REGION + (kq >> 1) * (PWU * 16) + (r >> 3) * (2 * ROWB) + (r & 7) * 16 + g0 * (4 * ROWB);
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+
+    // this wave stages region `wave` (plane = wave >> 1, channel half = wave & 1): piece k, lane l = linear unit 64 k + l of the region
+    auto issue_patch = [&](int t, int buf) {
+        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
+        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+        const int iy_base = ty * TH * 2 - p.pad_t, ix_base = tx * TW * 2 - p.pad_l;
+        const uint8_t* xin = p.x + (size_t)n * p.H * p.W * 64 + (wave >> 1) * 32 + (wave & 1) * 16;
+        uint8_t* dst = smem_p2 + buf * PATCH + wave * REGION;
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            const int L = k * 64 + lane;
+            const int py = (L * 3277) >> 16;                  // L / 20 for L < 704
+            const int rem = L - py * ROW_UNITS;
+            const int par = rem >= PWU ? 1 : 0, idx = rem - par * PWU;
+            const int iy = iy_base + py, ix = ix_base + 2 * idx + par;
+            const bool ok = py < PH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const uint8_t* src = ok ? xin + ((size_t)iy * p.W + ix) * 64 : p.zeros;
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + k * 1024), 16, 0, 0);
+        }
+    };
+
+    int t = blockIdx.x, buf = 0;
+    float vmax = 0.f;
+    if (t < p.ntiles) issue_patch(t, 0);
+    while (t < p.ntiles) {
+        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
+        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        // this tile's patch has landed; behind the barrier every wave has also left the previous tile's matrix phase,
+        // so the other buffer may be refilled: the next tile's patch flies under this tile's matrix phase and stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int tnext = t + gridDim.x;
+        if (tnext < p.ntiles) issue_patch(tnext, buf ^ 1);
+
+        const uint8_t* a0 = smem_p2 + buf * PATCH + a_lane;
+        f32x4 acc[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[g] = f32x4{bv, bv, bv, bv};
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step) {
+            const int ky = step / 3, h = step - 3 * ky;
+            const int aoff = ky * ROWB + h * 16;
+            const half8 bh = wreg[step][0], bl = wreg[step][1];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const half8 ah = lds_frag(a0 + aoff + g * (4 * ROWB));
+                const half8 al = lds_frag(a0 + aoff + g * (4 * ROWB) + 2 * REGION);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[g], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel 16 ng + r), row = 4 kq + i = pixel of the group:
+        // output row 2 g + (kq >> 1), column 4 (kq & 1) + i.  Even lanes store the hi halves of channels (c, c+1), odd lanes the
+        // lo halves of (c-1, c): one 4-byte store per value (as conv_patch_cnv1_h3)
+        const bool odd = r & 1;
+        const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+        const int cfull = 16 * ng + r;
+        const int choff = odd ? 64 + (cfull - 1) * 2 : cfull * 2;
+        const bool interior = oy0 + TH <= p.Ho && ox0 + TW <= p.Wo;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int oy = oy0 + 2 * (g0 + g) + (kq >> 1);
+            if (!interior && oy >= p.Ho) continue;
+            const int oxb = ox0 + 4 * (kq & 1);
+            uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + oxb) * 128 + choff;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = fmaxf(acc[g][i] * p.out_scale, 0.f);
+                const bool ok = interior || oxb + i < p.Wo;
+                if (ok) vmax = fmaxf(vmax, v);
+                v = fminf(v, 65504.f);
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                   ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                if (ok) *reinterpret_cast<unsigned*>(orow + i * 128) = __builtin_amdgcn_perm(xn, x, sel);
+            }
+        }
+        t = tnext;
+        buf ^= 1;
+    }
+    if (p.range) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        if (lane == 0 && __float_as_uint(vmax) > __atomic_load_n(p.range, __ATOMIC_RELAXED)) atomicMax(p.range, __float_as_uint(vmax));
+    }
+}
+
 }  // namespace davo

@@ -228,6 +228,28 @@ int run_cnv1_patch(davo_ctx* c, bool fused, const void* d_img, const void* d_flo
     return DAVO_OK;
 }
 
+// cnv2 of the f16x3 path from an LDS-staged input patch (conv_patch_h3.h, conv_patch_cnv2_h3)
+int run_cnv2_patch(davo_ctx* c, const void* x, void* y, int NB) {
+    const ConvLayer& L = c->L[1];
+    ConvPatchParams p{};
+    int Ho, Wo, pt, pl;
+    same_pad(c->H1, 5, 2, 1, &Ho, &pt);
+    same_pad(c->W1, 5, 2, 1, &Wo, &pl);
+    p.x = static_cast<const uint8_t*>(x); p.w = c->d_w2patch; p.bias = L.d_bh; p.y = static_cast<uint8_t*>(y);
+    p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
+    p.H = c->H1; p.W = c->W1; p.Ho = Ho; p.Wo = Wo; p.pad_t = pt; p.pad_l = pl;
+    p.tiles_x = (Wo + cp2::TW - 1) / cp2::TW; p.tiles_y = (Ho + cp2::TH - 1) / cp2::TH;
+    p.out_scale = ldexpf(1.0f / L.wscale, c->act_shift[1] - c->act_shift[0]);
+    p.bias_scale = ldexpf(L.wscale, c->act_shift[0]);
+    p.range = c->d_range ? c->d_range + 1 : nullptr;
+    p.ntiles = NB * p.tiles_x * p.tiles_y;
+    c->last_plan[1][0] = ((NB * Ho * Wo + 127) / 128) * 1000 + 98; c->last_plan[1][1] = 0;
+    const int nblk = p.ntiles < 2 * c->ncu ? p.ntiles : 2 * c->ncu;   // 2 workgroups per CU (120 weight registers per lane), each walks its tiles
+    ProfScope ps(c, "cnv2");
+    HIP_TRY(c, launch_cnv2_patch(p, nblk, c->stream));
+    return DAVO_OK;
+}
+
 int run_direct(davo_ctx* c, const char* label, const float* x, int N, int Hin, int Win, int cin, int x_ld,
                int x_coff, const std::string& wname, const std::string& bname, int KS, int cout, int stride,
                int rate, float* y, int y_ld, int y_coff) {
@@ -298,7 +320,9 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     if (h3) {
         if (patch1) { if ((rc = run_cnv1_patch(c, fused, d_img, d_flow, d_seg, a[0], NB))) return rc; }
         else if ((rc = run_conv_layer_h3(c, 0, c->d_packed, 8, H, W, a[0], 16, false, NB))) return rc;
-        if ((rc = run_conv_layer_h3(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, false, NB))) return rc;
+        const char* p2e = tuning_env("DAVO_CNV2_PATCH");
+        if (c->opt_patch_cnv2 && c->L[1].tile_h < 0 && !(p2e && atoi(p2e) == 0)) { if ((rc = run_cnv2_patch(c, a[0], a[1], NB))) return rc; }
+        else if ((rc = run_conv_layer_h3(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 3, a[2], 64, c->H2, c->W2, a[3], 128, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 4, a[3], 128, c->H2, c->W2, a[4], 256, false, NB))) return rc;

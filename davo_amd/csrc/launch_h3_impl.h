@@ -1,6 +1,7 @@
 // launch_h3_impl.h — templates shared by the two translation units that instantiate conv_igemm_h3
 // (launch_h3.hip: the seven PoseNN layers; launch_h3_generic.hip: davo_conv2d_same's generic shapes).
 #pragma once
+#include <cstdio>
 #include <cstdlib>
 
 #include "conv_igemm_h3.h"
@@ -47,6 +48,18 @@ hipError_t launch_m(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     auto kern = conv_igemm_h3<KS, STRIDE, WM, WN, TM, TN, LAYER, true, SMALLC, M16, NSTG>;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES_DMA);
     if (e != hipSuccess) return e;
+#ifdef DAVO_TUNING
+    if (tuning_env("DAVO_PRINT_OCC")) {          // tuning build only: resident workgroups per CU the runtime computes
+        static bool once = false;
+        if (!once) {
+            once = true;
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, T::THREADS, T::LDS_BYTES_DMA);
+            fprintf(stderr, "occupancy layer %d tile %dx%d stages %d: %d workgroups/CU (LDS %d B, grid %u)\n", LAYER, T::BMH, T::BNH, NSTG, nb,
+                    T::LDS_BYTES_DMA, grid.x * grid.y);
+        }
+    }
+#endif
     hipLaunchKernelGGL(kern, grid, dim3(T::THREADS), T::LDS_BYTES_DMA, s, p);
     return hipGetLastError();
 }

@@ -139,6 +139,23 @@ constexpr int LDS_BYTES = 2 * PLANE;                   // 43,008 B: the patch (t
 constexpr int THREADS = 256;
 }  // namespace cp1
 
+// ---- conv_patch_h3.h (cnv2 from an LDS patch) ---------------------------------------------
+namespace cp2 {
+constexpr int KS = 5, TH = 8, TW = 8;                  // filter, output tile: 4 pixel groups of 2 rows x 8 columns
+constexpr int PH = 2 * TH + KS - 2;                    // 19 input rows
+constexpr int PWU = TW + 2;                            // 16-byte units per column parity of a patch row (columns 0..19)
+constexpr int ROWB = 2 * PWU * 16;                     // 320 B per patch row: [even columns | odd columns], = 64 mod 128
+constexpr int ROW_UNITS = 2 * PWU;
+constexpr int REGION = (PH * ROWB + 255) / 256 * 256;  // 6,144 B per (plane, channel half) region, a multiple of 256
+constexpr int NDMA = (PH * ROW_UNITS + 63) / 64;       // 6 LDS-DMA wave-instructions per region
+constexpr int PATCH = 4 * REGION;                      // 24,576 B
+constexpr int LDS_BYTES = 2 * PATCH;                   // double-buffered: 49,152 B, three workgroups per CU
+constexpr int STEPS = KS * 3;                          // 15 MFMA steps: filter row x tap pair (kx = 5 is a zero-weight dummy)
+constexpr int WBYTES = STEPS * 2 * 2 * 64 * 16;        // [step][N group][plane][lane] x 16 B
+constexpr int THREADS = 256;
+static_assert(NDMA * 1024 <= REGION, "the last DMA piece stays inside its region");
+}  // namespace cp2
+
 struct ConvPatchParams {
     const uint8_t* x;       // packed split-fp16 input [NB][H][W][8 hi | 8 lo]
     const uint8_t* w;       // [14][2][64][8] halves: B fragments in lane order, pre-scaled

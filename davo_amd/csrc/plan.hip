@@ -80,7 +80,7 @@ TileShape tile_shape(int t) {
 // Round 2: 256x256 and 256x128 stage one pixel patch per filter row for its three taps on cnv3..cnv6 (-3 % and -6 %:
 // gpurun_out/ab_r02v.log, ab_r02w.log), which moves 256x128 past 128x128 where no round is left half empty (cnv4 at B=128).
 static TileInfo kTiles[] = {{TILE_256x256, 1, 1.00}, {TILE_128x256, 1, 0.82}, {TILE_256x128, 1, 0.89},
-                            {TILE_128x128, 2, 0.87}, {TILE_256x64, 1, 0.62}, {TILE_128x32, 3, 0.40}, {TILE_208x256, 1, 0.89}};
+                            {TILE_128x128, 2, 0.87}, {TILE_256x64, 2, 0.62}, {TILE_128x32, 4, 0.40}, {TILE_208x256, 1, 0.89}};
 
 // tuning build only: DAVO_H3_EFF="e0,e1,e2,e3,e4,e5[,p4]" (and DAVO_H3_EFF208=e) overrides the efficiencies (table order) and 256x64's per_cu
 static void tiles_from_env() {

@@ -292,6 +292,26 @@ int build_packed_weights_h3(davo_ctx* c) {
         int rc = upload_bytes(c, wp.data(), wp.size() * sizeof(_Float16), reinterpret_cast<void**>(&c->d_w1patch));
         if (rc) return rc;
     }
+    {   // cnv2 patch kernel: [15 steps = ky x tap pair h][N group][hi|lo][64 lanes][8 halves]; lane = (channel c = l&15,
+        // k-quarter kq = l>>4): tap kx = 2 h + (kq >> 1) (kx = 5: zero), input channels 8 (kq & 1) .. +7
+        const ConvLayer& L = c->L[1];
+        const HostTensor& t = W("pose_exp_net/cnv2/weights");            // [5][5][16][32]
+        std::vector<_Float16> wp((size_t)cp2::WBYTES / 2, (_Float16)0.0f);
+        for (int step = 0; step < cp2::STEPS; ++step)
+            for (int g = 0; g < 2; ++g)
+                for (int l = 0; l < 64; ++l) {
+                    const int n = 16 * g + (l & 15), kq = l >> 4, ky = step / 3, kx = 2 * (step % 3) + (kq >> 1);
+                    if (kx >= 5) continue;
+                    for (int j = 0; j < 8; ++j) {
+                        const int ci = 8 * (kq & 1) + j;
+                        const float v = t.data[(((size_t)ky * 5 + kx) * 16 + ci) * 32 + n] * L.wscale;
+                        const size_t base = ((size_t)(step * 2 + g) * 2) * 64;
+                        split_f16(v, &wp[(base + l) * 8 + j], &wp[(base + 64 + l) * 8 + j]);
+                    }
+                }
+        int rc = upload_bytes(c, wp.data(), wp.size() * sizeof(_Float16), reinterpret_cast<void**>(&c->d_w2patch));
+        if (rc) return rc;
+    }
     c->packed_h_ready = true;
     return DAVO_OK;
 }

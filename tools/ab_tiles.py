@@ -3,6 +3,7 @@
 of the flagship path with the f16x3 layers forced onto one tile shape (davo_set_option "force_tile") or planned.
 
     python tools/ab_tiles.py [--batch 32] [--tiles -1,5,6] [--rounds 3] [--steps 10] [--options k=v,...]
+    python tools/ab_tiles.py --arms "patch_cnv2=1;patch_cnv2=0"      # arms = option sets instead of tile shapes
 """
 import argparse
 import os
@@ -23,6 +24,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--options", default="", help="extra davo_set_option pairs applied to every arm, k=v,k=v")
+    ap.add_argument("--arms", default="", help="arms as option sets 'k=v,k=v;k=v,...' (interleaved in one process) instead of --tiles")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight (consecutive calls rotate through that many streams)")
     a = ap.parse_args()
     cfg = parse_version(FLAGSHIP_VERSION)
@@ -40,12 +42,22 @@ def main():
         k, v = kv.split("=")
         e.set_option(k, int(v))
     tiles = [int(t) for t in a.tiles.split(",")]
+    arm_opts = {}
+    if a.arms:
+        tiles = []
+        for spec in a.arms.split(";"):
+            tiles.append(spec)
+            arm_opts[spec] = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in filter(None, spec.split(","))]
     acc = {t: {} for t in tiles}
     wall = {t: [] for t in tiles}
     import time
     for rnd in range(a.rounds):
         for t in tiles:
-            e.set_option("force_tile", t)
+            if a.arms:
+                for k, v in arm_opts[t]:
+                    e.set_option(k, v)
+            else:
+                e.set_option("force_tile", t)
             for i in range(3 * a.inflight):
                 e.forward_device(B, *sets[i % a.inflight])
             e.synchronize()
@@ -66,7 +78,7 @@ def main():
         for k in acc[t]:
             if k not in names:
                 names.append(k)
-    print("B=%d %dx%d; ms per launch, median over %d rounds; columns = force_tile %s" % (B, H, W, a.rounds, tiles))
+    print("B=%d %dx%d; ms per launch, median over %d rounds; columns = %s %s" % (B, H, W, a.rounds, "options" if a.arms else "force_tile", tiles))
     for k in names:
         print("%-20s" % k + "".join("%10.4f" % (np.median(acc[t][k]) if k in acc[t] else float("nan")) for t in tiles))
     print("%-20s" % "step (wall, no events)" + "".join("%10.4f" % np.median(wall[t]) for t in tiles))
