@@ -306,4 +306,127 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
     }
 }
 
+// ---- cnv3 (3x3, dilation 2, 32 -> 64 channels) from an LDS patch ----------------------------------
+// As an implicit GEMM cnv3 has 9 chunks of 24 matrix instructions per wave between barriers: 0.046 ms at B=32 of which
+// 0.004 is matrix time, 0.025 the barrier / wait skeleton and 0.015 the stores all CUs issue together.  Same recipe as
+// conv_patch_cnv2_h3: the 12 x 12-pixel input patch of an 8 x 8 output tile is staged once (18 KB, double-buffered), the
+// A fragments come straight from it (K = 32 = one tap x 32 channels: a lane's fragment is channel quarter lane>>4 of one
+// pixel), wave w owns output channels 16 w .. +15 with its 18 weight fragments in registers, one barrier per tile.
+// Patch layout: eight regions [plane hi|lo][channel quarter], each [patch row][12 pixels] x 16 B.  A pixel group is two
+// output rows TWO apart x 8 columns (rows {0,2}, {1,3}, {4,6}, {5,7} of the tile): lanes 0-7 read 8 consecutive units,
+// lanes 8-15 the same units 384 B = 128 mod 256 further on; regions are multiples of 256 B: conflict-free.
+__global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchParams p) {
+    using namespace cp3;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_p3[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = N group: channels 16 wave .. +15
+    half8 wreg[STEPS][2];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 0) * 64 + lane) * 16);
+        wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 1) * 64 + lane) * 16);
+    }
+    const int r = lane & 15, kq = lane >> 4;
+    const float bv = p.bias[16 * wave + r] * p.bias_scale;              // C/D layout: col = lane & 15 = channel
+    // A fragment of group g, tap (ky, kx), plane pl: region (pl, kq), patch row (4 (g >> 1) + (g & 1) + 2 (r >> 3)) + 2 ky,
+    // pixel (r & 7) + 2 kx
+    const int a_lane = kq * REGION + (r >> 3) * (2 * ROWB) + (r & 7) * 16;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+
+    // piece k, lane l = linear 16-byte unit 64 k + l of the patch [region][row][pixel]; the waves take pieces k = wave, wave + 4, ...
+    auto issue_patch = [&](int t, int buf) {
+        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
+        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+        const int iy_base = ty * TH - p.pad_t, ix_base = tx * TW - p.pad_l;
+        const uint8_t* xin = p.x + (size_t)n * p.H * p.W * 128;
+        uint8_t* dst = smem_p3 + buf * PATCH;
+#pragma unroll
+        for (int kk = 0; kk < (NDMA + 3) / 4; ++kk) {
+            const int k = wave + 4 * kk;
+            if (k < NDMA) {
+                const int L = k * 64 + lane;
+                const int reg = L / (PH * PW), rem = L - reg * (PH * PW);
+                const int py = rem / PW, px = rem - py * PW;
+                const int iy = iy_base + py, ix = ix_base + px;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const uint8_t* src = ok ? xin + ((size_t)iy * p.W + ix) * 128 + (reg >> 2) * 64 + (reg & 3) * 16 : p.zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + k * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    int t = blockIdx.x, buf = 0;
+    float vmax = 0.f;
+    if (t < p.ntiles) issue_patch(t, 0);
+    while (t < p.ntiles) {
+        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
+        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        // this tile's patch has landed; behind the barrier every wave has also left the previous tile's matrix phase,
+        // so the other buffer may be refilled: the next tile's patch flies under this tile's matrix phase and stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int tnext = t + gridDim.x;
+        if (tnext < p.ntiles) issue_patch(tnext, buf ^ 1);
+
+        const uint8_t* a0 = smem_p3 + buf * PATCH + a_lane;
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{bv, bv, bv, bv};
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step) {
+            const int ky = step / 3, kx = step - 3 * ky;
+            const int aoff = ky * (RATE * ROWB) + kx * (RATE * 16);
+            const half8 bh = wreg[step][0], bl = wreg[step][1];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int goff = (4 * (g >> 1) + (g & 1)) * ROWB;
+                const half8 ah = lds_frag(a0 + aoff + goff);
+                const half8 al = lds_frag(a0 + aoff + goff + 4 * REGION);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[g], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);                 // fragments of at most one step ahead: three waves per SIMD need <= 168 registers
+        }
+
+        // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel 16 wave + r), row = 4 kq + i = pixel of the group:
+        // output row 4 (g >> 1) + (g & 1) + 2 (kq >> 1), column 4 (kq & 1) + i.  The 64 output channels are two blocks of
+        // [32 hi | 32 lo] halves; even lanes store the hi halves of channels (c, c+1), odd lanes the lo halves of (c-1, c)
+        const bool odd = r & 1;
+        const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+        const int cfull = 16 * wave + r, cin = cfull & 31;
+        const int choff = (cfull >> 5) * 128 + (odd ? 64 + (cin - 1) * 2 : cin * 2);
+        const bool interior = oy0 + TH <= p.Ho && ox0 + TW <= p.Wo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int oy = oy0 + 4 * (g >> 1) + (g & 1) + 2 * (kq >> 1);
+            if (!interior && oy >= p.Ho) continue;
+            const int oxb = ox0 + 4 * (kq & 1);
+            uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + oxb) * 256 + choff;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = fmaxf(acc[g][i] * p.out_scale, 0.f);
+                const bool ok = interior || oxb + i < p.Wo;
+                if (ok) vmax = fmaxf(vmax, v);
+                v = fminf(v, 65504.f);
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                   ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                if (ok) *reinterpret_cast<unsigned*>(orow + i * 256) = __builtin_amdgcn_perm(xn, x, sel);
+            }
+        }
+        t = tnext;
+        buf ^= 1;
+    }
+    if (p.range) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        if (lane == 0 && __float_as_uint(vmax) > __atomic_load_n(p.range, __ATOMIC_RELAXED)) atomicMax(p.range, __float_as_uint(vmax));
+    }
+}
+
 }  // namespace davo

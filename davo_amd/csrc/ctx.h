@@ -74,6 +74,7 @@ struct davo_ctx {
     bool opt_fuse_pose = true;                 // f16x3: pose head fused into cnv7's epilogue (davo_set_option)
     bool opt_fuse_pack = false;                // f16x3: mask+pack fused into cnv1's patch fill
     bool opt_patch_cnv2 = true;                // f16x3: cnv2 from an LDS-staged input patch (conv_patch_cnv2_h3) instead of the implicit GEMM
+    bool opt_patch_cnv3 = true;                // f16x3: cnv3 likewise (conv_patch_cnv3_h3)
     bool opt_share_taps = true;                // f16x3: cnv3..cnv6 stage one pixel patch per filter row for its three taps
     float* d_pose_tiles = nullptr;             // per-tile partial sums of the fused pose head
     size_t pose_tiles_floats = 0;
@@ -92,6 +93,7 @@ struct davo_ctx {
     float *d_wpred = nullptr, *d_bpred = nullptr;
     uint8_t* d_w1patch = nullptr;              // cnv1 B fragments for conv_patch_cnv1_h3
     uint8_t* d_w2patch = nullptr;              // cnv2 B fragments for conv_patch_cnv2_h3
+    uint8_t* d_w3patch = nullptr;              // cnv3 B fragments for conv_patch_cnv3_h3
     // geometry
     int H1, W1, H2, W2, H3, W3;
     // workspace

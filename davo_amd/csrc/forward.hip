@@ -250,6 +250,25 @@ int run_cnv2_patch(davo_ctx* c, const void* x, void* y, int NB) {
     return DAVO_OK;
 }
 
+// cnv3 of the f16x3 path from an LDS-staged input patch (conv_patch_h3.h, conv_patch_cnv3_h3)
+int run_cnv3_patch(davo_ctx* c, const void* x, void* y, int NB) {
+    const ConvLayer& L = c->L[2];
+    ConvPatchParams p{};
+    p.x = static_cast<const uint8_t*>(x); p.w = c->d_w3patch; p.bias = L.d_bh; p.y = static_cast<uint8_t*>(y);
+    p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
+    p.H = c->H2; p.W = c->W2; p.Ho = c->H2; p.Wo = c->W2; p.pad_t = cp3::RATE; p.pad_l = cp3::RATE;
+    p.tiles_x = (p.Wo + cp3::TW - 1) / cp3::TW; p.tiles_y = (p.Ho + cp3::TH - 1) / cp3::TH;
+    p.out_scale = ldexpf(1.0f / L.wscale, c->act_shift[2] - c->act_shift[1]);
+    p.bias_scale = ldexpf(L.wscale, c->act_shift[1]);
+    p.range = c->d_range ? c->d_range + 2 : nullptr;
+    p.ntiles = NB * p.tiles_x * p.tiles_y;
+    c->last_plan[2][0] = ((NB * p.Ho * p.Wo + 127) / 128) * 1000 + 97; c->last_plan[2][1] = 0;
+    const int nblk = p.ntiles < 3 * c->ncu ? p.ntiles : 3 * c->ncu;   // 3 workgroups per CU, each walks its tiles
+    ProfScope ps(c, "cnv3");
+    HIP_TRY(c, launch_cnv3_patch(p, nblk, c->stream));
+    return DAVO_OK;
+}
+
 int run_direct(davo_ctx* c, const char* label, const float* x, int N, int Hin, int Win, int cin, int x_ld,
                int x_coff, const std::string& wname, const std::string& bname, int KS, int cout, int stride,
                int rate, float* y, int y_ld, int y_coff) {
@@ -323,7 +342,9 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         const char* p2e = tuning_env("DAVO_CNV2_PATCH");
         if (c->opt_patch_cnv2 && c->L[1].tile_h < 0 && !(p2e && atoi(p2e) == 0)) { if ((rc = run_cnv2_patch(c, a[0], a[1], NB))) return rc; }
         else if ((rc = run_conv_layer_h3(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, false, NB))) return rc;
-        if ((rc = run_conv_layer_h3(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, false, NB))) return rc;
+        const char* p3e = tuning_env("DAVO_CNV3_PATCH");
+        if (c->opt_patch_cnv3 && c->L[2].tile_h < 0 && !(p3e && atoi(p3e) == 0)) { if ((rc = run_cnv3_patch(c, a[1], a[2], NB))) return rc; }
+        else if ((rc = run_conv_layer_h3(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 3, a[2], 64, c->H2, c->W2, a[3], 128, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 4, a[3], 128, c->H2, c->W2, a[4], 256, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 5, a[4], 256, c->H2, c->W2, a[5], 2 * c6, false, NB))) return rc;

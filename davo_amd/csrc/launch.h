@@ -35,6 +35,7 @@ hipError_t launch_mask_pack(int ld, const uint8_t* d_img, const float* d_flow, c
                             const Variant& v, int B, int H, int W, float* d_packed, hipStream_t s);
 hipError_t launch_cnv1_patch(bool fused, const ConvPatchParams& p, int nblk, hipStream_t s);
 hipError_t launch_cnv2_patch(const ConvPatchParams& p, int nblk, hipStream_t s);
+hipError_t launch_cnv3_patch(const ConvPatchParams& p, int nblk, hipStream_t s);
 hipError_t launch_pose_from_tiles(const float* d_tiles, int NB, int P, int bm, int mtiles, int ntiles_n,
                                   const float* d_bpred, float* d_pose, hipStream_t s);
 hipError_t launch_pose_head(const float* d_c7, int NB, int P, const float* d_wpred, const float* d_bpred,

@@ -62,6 +62,13 @@ hipError_t launch_cnv2_patch(const ConvPatchParams& p, int nblk, hipStream_t s) 
     return hipGetLastError();
 }
 
+hipError_t launch_cnv3_patch(const ConvPatchParams& p, int nblk, hipStream_t s) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_patch_cnv3_h3), cp3::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_patch_cnv3_h3, dim3(nblk), dim3(cp3::THREADS), cp3::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_pose_from_tiles(const float* d_tiles, int NB, int P, int bm, int mtiles, int ntiles_n,
                                   const float* d_bpred, float* d_pose, hipStream_t s) {
     hipLaunchKernelGGL(pose_from_tiles, dim3((NB * 6 + 63) / 64), dim3(64), 0, s, d_tiles, NB, P, bm, mtiles, ntiles_n, d_bpred, d_pose);

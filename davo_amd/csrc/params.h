@@ -156,6 +156,21 @@ constexpr int THREADS = 256;
 static_assert(NDMA * 1024 <= REGION, "the last DMA piece stays inside its region");
 }  // namespace cp2
 
+// ---- conv_patch_h3.h (cnv3 from an LDS patch) ---------------------------------------------
+namespace cp3 {
+constexpr int RATE = 2, TH = 8, TW = 8;                // 3x3, dilation 2, stride 1; output tile: 4 pixel groups of 2 rows x 8 columns
+constexpr int PH = TH + 2 * RATE, PW = TW + 2 * RATE;  // 12 x 12 input pixels
+constexpr int ROWB = PW * 16;                          // 192 B per patch row of a region; two rows = 384 B = 128 mod 256
+constexpr int REGION = PH * ROWB;                      // 2,304 B per (plane, channel quarter) region, a multiple of 256
+constexpr int PATCH = 8 * REGION;                      // 18,432 B = 18 LDS-DMA wave-instructions exactly
+constexpr int NDMA = PATCH / 1024;
+constexpr int LDS_BYTES = 2 * PATCH;                   // double-buffered: 36,864 B
+constexpr int STEPS = 9;                               // one tap x 32 channels per MFMA step
+constexpr int WBYTES = STEPS * 4 * 2 * 64 * 16;        // [step][N group][plane][lane] x 16 B
+constexpr int THREADS = 256;
+static_assert(REGION % 256 == 0 && PATCH % 1024 == 0 && (2 * ROWB) % 256 == 128, "bank-conflict-free fragment reads, whole DMA pieces");
+}  // namespace cp3
+
 struct ConvPatchParams {
     const uint8_t* x;       // packed split-fp16 input [NB][H][W][8 hi | 8 lo]
     const uint8_t* w;       // [14][2][64][8] halves: B fragments in lane order, pre-scaled

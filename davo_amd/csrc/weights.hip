@@ -312,6 +312,23 @@ int build_packed_weights_h3(davo_ctx* c) {
         int rc = upload_bytes(c, wp.data(), wp.size() * sizeof(_Float16), reinterpret_cast<void**>(&c->d_w2patch));
         if (rc) return rc;
     }
+    {   // cnv3 patch kernel: [9 taps][4 N groups][hi|lo][64 lanes][8 halves]; lane = (channel c = l&15, channel quarter kq = l>>4)
+        const ConvLayer& L = c->L[2];
+        const HostTensor& t = W("pose_exp_net/cnv3/weights");            // [3][3][32][64]
+        std::vector<_Float16> wp((size_t)cp3::WBYTES / 2, (_Float16)0.0f);
+        for (int step = 0; step < cp3::STEPS; ++step)
+            for (int g = 0; g < 4; ++g)
+                for (int l = 0; l < 64; ++l) {
+                    const int n = 16 * g + (l & 15), kq = l >> 4;
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = t.data[((size_t)step * 32 + 8 * kq + j) * 64 + n] * L.wscale;
+                        const size_t base = ((size_t)(step * 4 + g) * 2) * 64;
+                        split_f16(v, &wp[(base + l) * 8 + j], &wp[(base + 64 + l) * 8 + j]);
+                    }
+                }
+        int rc = upload_bytes(c, wp.data(), wp.size() * sizeof(_Float16), reinterpret_cast<void**>(&c->d_w3patch));
+        if (rc) return rc;
+    }
     c->packed_h_ready = true;
     return DAVO_OK;
 }

@@ -155,8 +155,9 @@ int davo_set_activation_shifts(davo_ctx* ctx, const int* shifts);
  *   "fuse_pose" (default 1): pred 1x1 + spatial mean + 0.01 (nets/posenn.py:240-250) run in cnv7's
  *       epilogue; the cnv7 activation is never written to HBM.  0 = cnv7 stored, separate pose-head kernels.
  *   "fuse_pack" (default 0): cnv1 builds its input patch from the raw inputs (mask + pack fused in).
- *   "patch_cnv2" (default 1): cnv2 reads its 5x5 stride-2 taps from an LDS-staged input patch (csrc/conv_patch_h3.h);
- *       0 = the implicit-GEMM kernel.  The two sum a pixel's taps in different orders: poses agree to float32 rounding.
+ *   "patch_cnv2", "patch_cnv3" (default 1): cnv2 (5x5 stride 2) / cnv3 (3x3 dilation 2) read their taps from an LDS-staged
+ *       input patch (csrc/conv_patch_h3.h); 0 = the implicit-GEMM kernel.  The two sum a pixel's taps in different orders:
+ *       poses agree to float32 rounding.
  *   "force_tile" (test hook, default -1 = the launch planner decides): tile id of csrc/plan.h (0 128x32, 1 256x64,
  *       2 256x128, 3 128x256, 4 128x128, 5 256x256, 6 208x256); every f16x3 layer the tile fits is issued as one
  *       launch of that shape.  Poses do not depend on it beyond float32 rounding of the fused pose head's sums.
