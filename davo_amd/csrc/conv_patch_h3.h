@@ -202,12 +202,6 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ng = wave & 1, g0 = 2 * (wave >> 1);
-    half8 wreg[STEPS][2];
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-        wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 0) * 64 + lane) * 16);
-        wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 1) * 64 + lane) * 16);
-    }
     const int r = lane & 15, kq = lane >> 4;
     const float bv = p.bias[16 * ng + r] * p.bias_scale;       // C/D layout: col = lane & 15 = channel
     // A fragment of group g, step (ky, h), plane pl:  region (pl, kq & 1), patch row 2 (2 g + (r >> 3)) + ky, parity kq >> 1
@@ -237,14 +231,24 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
 
     int t = blockIdx.x, buf = 0;
     float vmax = 0.f;
+    bool stores_counted = false;       // the previous tile issued exactly 8 stores per lane after this tile's patch DMA (interior tile)
     if (t < p.ntiles) issue_patch(t, 0);
+    // the wave's 30 weight fragments (30 KB) are fetched behind the first patch's DMA
+    half8 wreg[STEPS][2];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 0) * 64 + lane) * 16);
+        wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 1) * 64 + lane) * 16);
+    }
     while (t < p.ntiles) {
         const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
         const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
-        // this tile's patch has landed; behind the barrier every wave has also left the previous tile's matrix phase,
-        // so the other buffer may be refilled: the next tile's patch flies under this tile's matrix phase and stores
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this tile's patch has landed (vmcnt counts in issue order and the previous tile's stores are younger than this
+        // patch's DMA: they may stay in flight); behind the barrier every wave has also left the previous tile's matrix
+        // phase, so the other buffer may be refilled: the next tile's patch flies under this tile's matrix phase and stores
+        if (stores_counted) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int tnext = t + gridDim.x;
         if (tnext < p.ntiles) issue_patch(tnext, buf ^ 1);
@@ -275,25 +279,46 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
         const unsigned sel = odd ? 0x03020706u : 0x05040100u;
         const int cfull = 16 * ng + r;
         const int choff = odd ? 64 + (cfull - 1) * 2 : cfull * 2;
-        const bool interior = oy0 + TH <= p.Ho && ox0 + TW <= p.Wo;
+        const bool interior = oy0 + TH <= p.Ho && ox0 + TW <= p.Wo;   // uniform; every tile of a 128x416 / 256x832 frame
+        stores_counted = interior;
+        if (interior) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int oy = oy0 + 2 * (g0 + g) + (kq >> 1);
-            if (!interior && oy >= p.Ho) continue;
-            const int oxb = ox0 + 4 * (kq & 1);
-            uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + oxb) * 128 + choff;
+            for (int g = 0; g < 2; ++g) {
+                const int oy = oy0 + 2 * (g0 + g) + (kq >> 1);
+                uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0 + 4 * (kq & 1)) * 128 + choff;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = fmaxf(acc[g][i] * p.out_scale, 0.f);
-                const bool ok = interior || oxb + i < p.Wo;
-                if (ok) vmax = fmaxf(vmax, v);
-                v = fminf(v, 65504.f);
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
-                                   ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                if (ok) *reinterpret_cast<unsigned*>(orow + i * 128) = __builtin_amdgcn_perm(xn, x, sel);
+                for (int i = 0; i < 4; ++i) {
+                    float v = fmaxf(acc[g][i] * p.out_scale, 0.f);
+                    vmax = fmaxf(vmax, v);
+                    v = fminf(v, 65504.f);
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                    *reinterpret_cast<unsigned*>(orow + i * 128) = __builtin_amdgcn_perm(xn, x, sel);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int oy = oy0 + 2 * (g0 + g) + (kq >> 1);
+                if (oy >= p.Ho) continue;
+                const int oxb = ox0 + 4 * (kq & 1);
+                uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + oxb) * 128 + choff;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = fmaxf(acc[g][i] * p.out_scale, 0.f);
+                    const bool ok = oxb + i < p.Wo;
+                    if (ok) vmax = fmaxf(vmax, v);
+                    v = fminf(v, 65504.f);
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+                    if (ok) *reinterpret_cast<unsigned*>(orow + i * 128) = __builtin_amdgcn_perm(xn, x, sel);
+                }
             }
         }
         t = tnext;
@@ -321,12 +346,6 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = N group: channels 16 wave .. +15
-    half8 wreg[STEPS][2];
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-        wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 0) * 64 + lane) * 16);
-        wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 1) * 64 + lane) * 16);
-    }
     const int r = lane & 15, kq = lane >> 4;
     const float bv = p.bias[16 * wave + r] * p.bias_scale;              // C/D layout: col = lane & 15 = channel
     // A fragment of group g, tap (ky, kx), plane pl: region (pl, kq), patch row (4 (g >> 1) + (g & 1) + 2 (r >> 3)) + 2 ky,
@@ -358,14 +377,24 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
 
     int t = blockIdx.x, buf = 0;
     float vmax = 0.f;
+    bool stores_counted = false;       // the previous tile issued exactly 16 stores per lane after this tile's patch DMA (interior tile)
     if (t < p.ntiles) issue_patch(t, 0);
+    // the wave's 18 weight fragments (18 KB) are fetched behind the first patch's DMA
+    half8 wreg[STEPS][2];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 0) * 64 + lane) * 16);
+        wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 1) * 64 + lane) * 16);
+    }
     while (t < p.ntiles) {
         const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
         const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
-        // this tile's patch has landed; behind the barrier every wave has also left the previous tile's matrix phase,
-        // so the other buffer may be refilled: the next tile's patch flies under this tile's matrix phase and stores
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this tile's patch has landed (the previous tile's stores are younger than its DMA and may stay in flight);
+        // behind the barrier every wave has also left the previous tile's matrix phase, so the other buffer may be
+        // refilled: the next tile's patch flies under this tile's matrix phase and stores
+        if (stores_counted) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int tnext = t + gridDim.x;
         if (tnext < p.ntiles) issue_patch(tnext, buf ^ 1);
@@ -398,25 +427,46 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
         const unsigned sel = odd ? 0x03020706u : 0x05040100u;
         const int cfull = 16 * wave + r, cin = cfull & 31;
         const int choff = (cfull >> 5) * 128 + (odd ? 64 + (cin - 1) * 2 : cin * 2);
-        const bool interior = oy0 + TH <= p.Ho && ox0 + TW <= p.Wo;
+        const bool interior = oy0 + TH <= p.Ho && ox0 + TW <= p.Wo;   // uniform; every tile of a 128x416 / 256x832 frame
+        stores_counted = interior;
+        if (interior) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int oy = oy0 + 4 * (g >> 1) + (g & 1) + 2 * (kq >> 1);
-            if (!interior && oy >= p.Ho) continue;
-            const int oxb = ox0 + 4 * (kq & 1);
-            uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + oxb) * 256 + choff;
+            for (int g = 0; g < 4; ++g) {
+                const int oy = oy0 + 4 * (g >> 1) + (g & 1) + 2 * (kq >> 1);
+                uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0 + 4 * (kq & 1)) * 256 + choff;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = fmaxf(acc[g][i] * p.out_scale, 0.f);
-                const bool ok = interior || oxb + i < p.Wo;
-                if (ok) vmax = fmaxf(vmax, v);
-                v = fminf(v, 65504.f);
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
-                                   ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                if (ok) *reinterpret_cast<unsigned*>(orow + i * 256) = __builtin_amdgcn_perm(xn, x, sel);
+                for (int i = 0; i < 4; ++i) {
+                    float v = fmaxf(acc[g][i] * p.out_scale, 0.f);
+                    vmax = fmaxf(vmax, v);
+                    v = fminf(v, 65504.f);
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                    *reinterpret_cast<unsigned*>(orow + i * 256) = __builtin_amdgcn_perm(xn, x, sel);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int oy = oy0 + 4 * (g >> 1) + (g & 1) + 2 * (kq >> 1);
+                if (oy >= p.Ho) continue;
+                const int oxb = ox0 + 4 * (kq & 1);
+                uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + oxb) * 256 + choff;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = fmaxf(acc[g][i] * p.out_scale, 0.f);
+                    const bool ok = oxb + i < p.Wo;
+                    if (ok) vmax = fmaxf(vmax, v);
+                    v = fminf(v, 65504.f);
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+                    if (ok) *reinterpret_cast<unsigned*>(orow + i * 256) = __builtin_amdgcn_perm(xn, x, sel);
+                }
             }
         }
         t = tnext;

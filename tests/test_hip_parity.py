@@ -758,6 +758,42 @@ def test_tile_208x256_forced(c_oracle, B, H, W):
     e.close()
 
 
+# ---- cnv2 / cnv3 from LDS-staged input patches (conv_patch_cnv2_h3, conv_patch_cnv3_h3) -------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 128, 416), (3, 64, 96), (2, 36, 100), (1, 52, 172), (5, 20, 48), (1, 256, 832)])
+def test_patch_kernels_match_implicit_gemm(c_oracle, B, H, W):
+    """cnv2 and cnv3 read their taps from a double-buffered LDS patch of an 8x8 output tile (weights in registers, one
+    barrier per tile) instead of gathering 13 / 9 chunks per tile.  Same products, another summation order: the
+    activations agree with the implicit-GEMM kernels' to float32 rounding and the poses with the oracle, at whole tiles
+    (128x416, 256x832) and at maps that leave partial tiles in both directions (9x25, 13x43, 5x12 pixels)."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(B, H, W, first_window=23)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    e = _engine(cfg, H, W, B, weights, "f16x3")
+    h2, w2 = -(-H // 4), -(-W // 4)
+    e.set_option("patch_cnv2", 0)
+    e.set_option("patch_cnv3", 0)
+    base = e.forward(img, flow, seg).copy()
+    assert e.last_plan(1)[0][1] < 90 and e.last_plan(2)[0][1] < 90          # tile ids of the implicit-GEMM kernel
+    a2 = e.debug_read("cnv2", (2 * B, h2, w2, 32)).copy()
+    a3 = e.debug_read("cnv3", (2 * B, h2, w2, 64)).copy()
+    for k2, k3 in ((1, 0), (0, 1), (1, 1)):
+        e.set_option("patch_cnv2", k2)
+        e.set_option("patch_cnv3", k3)
+        got = e.forward(img, flow, seg)
+        assert (e.last_plan(1)[0][1] == 98) == bool(k2) and (e.last_plan(2)[0][1] == 97) == bool(k3)
+        b2 = e.debug_read("cnv2", (2 * B, h2, w2, 32))
+        b3 = e.debug_read("cnv3", (2 * B, h2, w2, 64))
+        assert np.abs(b2 - a2).max() <= 2e-6 * np.abs(a2).max(), (k2, k3)
+        assert np.abs(b3 - a3).max() <= 2e-6 * np.abs(a3).max(), (k2, k3)
+        if not k2:
+            assert np.array_equal(b2, a2)
+        assert np.abs(got - base).max() <= 2e-6 * np.abs(base).max()
+        assert_pose_close(got, want, "patch kernels %d%d" % (k2, k3))
+    e.close()
+
+
 # ---- shared-tap staging (conv_igemm_h3 RATE > 0) ---------------------------------------------------------
 @pytest.mark.parametrize("B,H,W", [(1, 128, 416), (5, 128, 416), (3, 64, 96), (2, 36, 100), (2, 20, 48), (1, 256, 832)])
 def test_shared_tap_staging_is_bit_identical(c_oracle, B, H, W):
