@@ -33,14 +33,19 @@ namespace davo {
 #define HS_DBG(bit_) false
 #endif
 
-template <int KS, int STRIDE, int LAYER>
+// NSA = ring slots of the PIXEL operand (the weights always have two).  3 for cnv7: its stride-2 gather misses L2 on the
+// first touch of every 128-byte pixel slice (0.151 -> 0.140 ms with the input pinned in L2), so its pixel DMA is issued two
+// chunks ahead; the weight DMA of chunk q+1 is issued BEFORE the pixel DMA of chunk q+2, so that "all but the newest
+// four" (vmcnt counts in issue order) is exactly what chunk q+1 needs.
+template <int KS, int STRIDE, int LAYER, int NSA = 2>
 __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
     using T = TileS;
     constexpr int NP = T::NP;
+    static_assert(NSA == 2 || NSA == 3, "pixel ring slots");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_s[];
-    uint8_t* As = smem_s;                              // [2][208][128]  pixels
-    uint8_t* Bs = smem_s + 2 * T::A_SLOT;              // [2][256][128]  weights
-    uint8_t* dummy = smem_s + 2 * (T::A_SLOT + T::B_SLOT);
+    uint8_t* As = smem_s;                              // [NSA][208][128]  pixels
+    uint8_t* Bs = smem_s + NSA * T::A_SLOT;            // [2][256][128]  weights
+    uint8_t* dummy = smem_s + NSA * T::A_SLOT + 2 * T::B_SLOT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -105,14 +110,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
 
     int dma_cblk = 0, dma_tq = 0;
     // chunk q = (channel block cblk, tap tq): the tap is uniform over the workgroup, the walk is scalar
-#define HS_DMA_SETUP(q_, buf_)                                                                     \
+    // the pixel walk (dma_cblk, dma_tq) points at the chunk whose pixels are fetched next (NSA - 1 ahead of the chunk being
+    // computed); qb_ = the chunk whose weights are fetched (one ahead)
+#define HS_DMA_SETUP(qb_, abuf_, bbuf_)                                                            \
         const int ky = dma_tq / KS, kx = dma_tq - ky * KS;                                         \
         const int dy = dma_on ? ky * p.rate : -(1 << 28), dx = kx * p.rate;                        \
         const long delta = ((long)dy * p.Win + dx) * p.x_pix_bytes + (long)dma_cblk * 128;         \
-        uint8_t* a_ = As + (buf_) * T::A_SLOT + a_row_off;                                         \
-        uint8_t* b_ = Bs + (buf_) * T::B_SLOT + a_row_off;                                         \
+        uint8_t* a_ = As + (abuf_) * T::A_SLOT + a_row_off;                                        \
+        uint8_t* b_ = Bs + (bbuf_) * T::B_SLOT + a_row_off;                                        \
         uint8_t* a3_ = wave_u < 2 ? a_ + 192 * 128 : a3_dst_fixed;                                 \
-        const uint8_t* wq = wg + (long)((q_) < p.nchunks ? (q_) : p.nchunks - 1) * 128;
+        const uint8_t* wq = wg + (long)((qb_) < p.nchunks ? (qb_) : p.nchunks - 1) * 128;
 #define HS_DMA_A(j_)                                                                               \
     {                                                                                              \
         const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
@@ -122,16 +129,28 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
     }
 #define HS_DMA_B(j_)                                                                               \
     __builtin_amdgcn_global_load_lds((gptr_t*)(wq + boff[j_]), (lptr_t*)(b_ + (j_) * 64 * 128), 16, 0, 0);
+    // NSA == 3: the four weight loads first, so the counted wait at the end of the chunk can leave the pixel loads in flight
 #define HS_DMA_SLOT(s_)                                                                            \
     {                                                                                              \
-        if constexpr ((s_) == 0) HS_DMA_A(0)                                                       \
-        if constexpr ((s_) == 1) HS_DMA_B(0)                                                       \
-        if constexpr ((s_) == 2) HS_DMA_A(1)                                                       \
-        if constexpr ((s_) == 3) HS_DMA_B(1)                                                       \
-        if constexpr ((s_) == 4) HS_DMA_A(2)                                                       \
-        if constexpr ((s_) == 5) HS_DMA_B(2)                                                       \
-        if constexpr ((s_) == 6) HS_DMA_A(3)                                                       \
-        if constexpr ((s_) == 7) HS_DMA_B(3)                                                       \
+        if constexpr (NSA == 2) {                                                                  \
+            if constexpr ((s_) == 0) HS_DMA_A(0)                                                   \
+            if constexpr ((s_) == 1) HS_DMA_B(0)                                                   \
+            if constexpr ((s_) == 2) HS_DMA_A(1)                                                   \
+            if constexpr ((s_) == 3) HS_DMA_B(1)                                                   \
+            if constexpr ((s_) == 4) HS_DMA_A(2)                                                   \
+            if constexpr ((s_) == 5) HS_DMA_B(2)                                                   \
+            if constexpr ((s_) == 6) HS_DMA_A(3)                                                   \
+            if constexpr ((s_) == 7) HS_DMA_B(3)                                                   \
+        } else {                                                                                   \
+            if constexpr ((s_) == 0) HS_DMA_B(0)                                                   \
+            if constexpr ((s_) == 1) HS_DMA_B(1)                                                   \
+            if constexpr ((s_) == 2) HS_DMA_B(2)                                                   \
+            if constexpr ((s_) == 3) HS_DMA_B(3)                                                   \
+            if constexpr ((s_) == 4) HS_DMA_A(0)                                                   \
+            if constexpr ((s_) == 5) HS_DMA_A(1)                                                   \
+            if constexpr ((s_) == 6) HS_DMA_A(2)                                                   \
+            if constexpr ((s_) == 7) HS_DMA_A(3)                                                   \
+        }                                                                                          \
     }
 #define HS_DMA_ADVANCE if (++dma_tq == p.cpb) { dma_tq = 0; ++dma_cblk; }
 
@@ -197,10 +216,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
-#define HS_CHUNK(buf_, nbuf_, q_)                                                                  \
+#define HS_CHUNK(abuf_, anbuf_, bbuf_, q_)                                                         \
     {                                                                                              \
-        const unsigned x0 = lds_u32(As + (buf_) * T::A_SLOT + l16 * 128);                          \
-        const unsigned w0 = lds_u32(Bs + (buf_) * T::B_SLOT + (wave_u * 32 + l16) * 128);          \
+        const unsigned x0 = lds_u32(As + (abuf_) * T::A_SLOT + l16 * 128);                         \
+        const unsigned w0 = lds_u32(Bs + (bbuf_) * T::B_SLOT + (wave_u * 32 + l16) * 128);         \
         const unsigned x_h = x0 + f_hi, x_l = x0 + f_lo, w_h = w0 + f_hi, w_l = w0 + f_lo;         \
         half8 wh0, wl0, wh1, wl1, xa_h, xa_l, xb_h, xb_l, xc_h, xc_l;                              \
         HS_RD(wh0, w_h, 0);                                                                        \
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
         HS_RD(xb_l, x_l, 16 * 128);                                                                \
         /* the scalar walk to the next chunk (tap, channel block, addresses) runs behind the reads it does not feed */ \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        HS_DMA_SETUP((q_) + 1, nbuf_)                                                              \
+        HS_DMA_SETUP((q_) + 1, anbuf_, (bbuf_) ^ 1)                                                \
         HS_GROUP(0, xa_h, xa_l, xc_h, xc_l)   HS_GROUP(1, xb_h, xb_l, xa_h, xa_l)   HS_GROUP(2, xc_h, xc_l, xb_h, xb_l) \
         HS_GROUP(3, xa_h, xa_l, xc_h, xc_l)   HS_GROUP(4, xb_h, xb_l, xa_h, xa_l)   HS_GROUP(5, xc_h, xc_l, xb_h, xb_l) \
         HS_GROUP(6, xa_h, xa_l, xc_h, xc_l)   HS_GROUP(7, xb_h, xb_l, xa_h, xa_l)   HS_GROUP(8, xc_h, xc_l, xb_h, xb_l) \
@@ -223,26 +242,45 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
     }
 
     constexpr int WAIT_ALL = (7 << 4) | (15 << 8);                   // vmcnt(0) only
+    constexpr int WAIT_KEEP_A = 4 | (7 << 4) | (15 << 8);            // vmcnt(4): this iteration's four pixel loads stay in flight
     {
-        // 2-slot LDS ring.  Chunk 0 is fetched up front; chunk q+1's DMA is issued from inside the matrix groups of
-        // chunk q (its address arithmetic in the shadow of queued MFMAs), waited for with vmcnt(0) and published by
-        // the raw s_barrier at the end of the iteration.  The slot refilled in iteration q was last read in
-        // iteration q-1, which every wave left through the previous barrier.
+        // LDS rings: 2 weight slots, NSA pixel slots.  Chunks 0 (.. NSA-2) are fetched up front; in iteration q the weights
+        // of chunk q+1 and the pixels of chunk q+NSA-1 are issued from inside the matrix groups of chunk q (address
+        // arithmetic in the shadow of queued MFMAs); the end of the iteration waits for everything chunk q+1 reads and
+        // publishes it with the raw s_barrier.  A slot refilled in iteration q was last read in iteration q-1, which every
+        // wave left through the previous barrier.
         {
             constexpr bool dma_on = true;
-            HS_DMA_SETUP(0, 0)
-            HS_DMA_A(0) HS_DMA_A(1) HS_DMA_A(2) HS_DMA_A(3) HS_DMA_B(0) HS_DMA_B(1) HS_DMA_B(2) HS_DMA_B(3)
-            HS_DMA_ADVANCE
+            {
+                HS_DMA_SETUP(0, 0, 0)
+                HS_DMA_A(0) HS_DMA_A(1) HS_DMA_A(2) HS_DMA_A(3) HS_DMA_B(0) HS_DMA_B(1) HS_DMA_B(2) HS_DMA_B(3)
+                HS_DMA_ADVANCE
+            }
+            if constexpr (NSA == 3) {
+                if (p.nchunks > 1) {
+                    HS_DMA_SETUP(0, 1, 0)
+                    (void)b_; (void)wq;
+                    HS_DMA_A(0) HS_DMA_A(1) HS_DMA_A(2) HS_DMA_A(3)
+                }
+                HS_DMA_ADVANCE
+            }
         }
         __builtin_amdgcn_s_waitcnt(WAIT_ALL);
         __builtin_amdgcn_s_barrier();
+        int aslot = 0;
         for (int q = 0; q < p.nchunks; ++q) {
-            // the last chunk has nothing to prefetch: its DMA slots fail every bounds test (zero line) and re-load
+            // the last chunk(s) have nothing to prefetch: their DMA slots fail every bounds test (zero line) and re-load
             // the last weight chunk into the idle slot instead of branching around the interleaved code
-            const bool dma_on = q + 1 < p.nchunks && !HS_DBG(1);
-            const int slot = q & 1;
-            HS_CHUNK(slot, slot ^ 1, q)
-            __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+            const bool dma_on = q + NSA - 1 < p.nchunks && !HS_DBG(1);
+            const int anext = NSA == 2 ? (aslot ^ 1) : (aslot == 0 ? 2 : aslot - 1);     // slot of chunk q + NSA - 1 = (q - 1) mod NSA
+            HS_CHUNK(aslot, anext, q & 1, q)
+            if constexpr (NSA == 3) __builtin_amdgcn_s_waitcnt(WAIT_KEEP_A);
+            else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+            __builtin_amdgcn_s_barrier();
+            aslot = NSA == 2 ? (aslot ^ 1) : (aslot == 2 ? 0 : aslot + 1);
+        }
+        if constexpr (NSA == 3) {
+            __builtin_amdgcn_s_waitcnt(WAIT_ALL);                    // the last iteration's filler loads must land before LDS is reused
             __builtin_amdgcn_s_barrier();
         }
     }

@@ -124,6 +124,7 @@ struct TileS {
     static constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128;
     static constexpr int DUMMY = WAVES * 1024;         // where the waves without a 4th pixel-row load park theirs
     static constexpr int LDS_BYTES = 2 * (A_SLOT + B_SLOT) + DUMMY;
+    static constexpr int lds_bytes(int nsa) { return nsa * A_SLOT + 2 * B_SLOT + DUMMY; }   // nsa pixel ring slots (conv_igemm_h3s NSA)
 };
 
 // ---- conv_patch_h3.h (cnv1 from an LDS patch) ---------------------------------------------

@@ -76,11 +76,12 @@ TileShape tile_shape(int t) {
 // one tile shape each, re-measured after the matrix loop was software-pipelined).  The two narrow tiles keep the
 // figures fitted on the K < 600 layers that use them (cnv3, cnv4: A/B on one box, profiles/ r01f notes).
 // The 208x256 tile (conv_igemm_h3s.h) is offered only to the layers it is instantiated for and only as a single launch;
-// 0.91: cnv6 at B=128 (16 whole rounds) 2.168 ms against 1.996 ms on 13 rounds of 256x256 (gpurun_out/ab_r02d.log).
+// 0.93: cnv6 at B=128 (16 whole rounds) 1.995 ms against 1.869 ms on 13 rounds of 256x256, cnv5 1.071 against 0.997 (three pixel
+// ring slots on the 208 tile, shared-tap staging on the 256 tile).
 // Round 2: 256x256 and 256x128 stage one pixel patch per filter row for its three taps on cnv3..cnv6 (-3 % and -6 %:
 // gpurun_out/ab_r02v.log, ab_r02w.log), which moves 256x128 past 128x128 where no round is left half empty (cnv4 at B=128).
 static TileInfo kTiles[] = {{TILE_256x256, 1, 1.00}, {TILE_128x256, 1, 0.82}, {TILE_256x128, 1, 0.89},
-                            {TILE_128x128, 2, 0.87}, {TILE_256x64, 2, 0.62}, {TILE_128x32, 4, 0.40}, {TILE_208x256, 1, 0.89}};
+                            {TILE_128x128, 2, 0.87}, {TILE_256x64, 2, 0.62}, {TILE_128x32, 4, 0.40}, {TILE_208x256, 1, 0.93}};
 
 // tuning build only: DAVO_H3_EFF="e0,e1,e2,e3,e4,e5[,p4]" (and DAVO_H3_EFF208=e) overrides the efficiencies (table order) and 256x64's per_cu
 static void tiles_from_env() {
