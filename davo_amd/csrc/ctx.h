@@ -1,6 +1,6 @@
 // ctx.h — host-side state of one davo_ctx (include/davo_hip.h) and the small helpers every
 // translation unit of libdavo_hip.so shares.  Host code only; the kernels live in conv_igemm.h,
-// conv_igemm_h3.h, conv_patch_h3.h and prologue.h and are launched through launch.h.
+// conv_igemm_h3.h, conv_igemm_h3s.h, conv_patch_h3.h and prologue.h and are launched through launch.h.
 //
 // Translation units (built in parallel by davo_amd/_lib.py, linked into one shared library):
 //   api.hip         extern "C" entry points (context, weights, forward, calibration, test hooks)
@@ -9,7 +9,8 @@
 //   weights.hip     weight re-layout: HWIO float32 -> packed f32 / split-fp16 operands
 //   launch_f32.hip  conv_igemm_f32 instantiations + dispatch
 //   launch_h3.hip   conv_igemm_h3 instantiations + dispatch (the f16x3 path, the long compile)
-//   launch_misc.hip prologue / pose head / cnv1 patch / direct-convolution kernels + dispatch
+//   launch_h3s.hip  conv_igemm_h3s instantiations (208x256 tile); launch_h3_generic.hip: davo_conv2d_same's shapes
+//   launch_misc.hip prologue / pose head / cnv1..cnv3 patch / direct-convolution kernels + dispatch
 //   comm.hip        RCCL communicator behind the C ABI (pose gather of the window-sharded driver)
 #pragma once
 #include <hip/hip_runtime.h>
