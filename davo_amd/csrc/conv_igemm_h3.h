@@ -172,7 +172,11 @@ void conv_igemm_h3(ConvParamsH p) {
     int xyv[XSLOTS];                                         // input row at ky = 0 (y - RATE), or far out of range: never valid
     unsigned xkeep = 0xffffu;                                // bit i: row group i keeps tap kx = 0 (x >= RATE); bit 8+i: keeps kx = 2
     const int xrow0 = wm * TM * 32 + (lane & 15);            // first fragment row of this lane inside the tile
-    const uint8_t* xgu = xg + unit_boff;
+    // The shared patch is read kx*RATE rows down, and under the (row >> 1) & 7 swizzle of the other LDS images a shift of
+    // 2 (mod 4) rows puts two k-quarters of a ds_read_b128 service group on the same banks (dilation 2: 6 M conflict cycles
+    // per cnv6 launch).  The patch therefore has its own swizzle, unit ^ (row & 6): conflict-free at every even shift.
+    const int ux = (tid & 7) ^ (r0 & 6);
+    const uint8_t* xgu = xg + ((ux >> 2) * (cb * 2) + (((ux & 3) * 8) & (cb - 1)) * 2);
     if constexpr (XS) {
         const int hw = p.Hout * p.Wout;
 #pragma unroll
@@ -196,7 +200,7 @@ void conv_igemm_h3(ConvParamsH p) {
         }
     }
     // A fragment byte offset (plane 0 = hi, 1 = lo) of tap kx from the patch base: row xrow0 + kx*RATE, unit swizzled by its row
-#define H3_XFRAG(KX_, PL_) ((unsigned)((xrow_ + (KX_) * RATE) * 128 + ((((PL_) * 4 + (lane >> 4)) ^ (((xrow_ + (KX_) * RATE) >> 1) & 7)) * 16)))
+#define H3_XFRAG(KX_, PL_) ((unsigned)((xrow_ + (KX_) * RATE) * 128 + ((((PL_) * 4 + (lane >> 4)) ^ ((xrow_ + (KX_) * RATE) & 6)) * 16)))
     // A fragment of row group I_ for tap KX_: the patch row, or the zero row for the lanes the tap carries out of the image row
 #define H3_XRD(arr_, I_, base_, KX_)                                                               \
     {                                                                                              \
