@@ -25,6 +25,24 @@
 
 namespace davo {
 
+// Tile walk of the persistent patch kernels.  Workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own, so
+// XCD x = id % 8 walks the CONTIGUOUS tile range [x * per, (x + 1) * per): tiles whose patches overlap (the halo is 1.5x - 2x
+// the input) are staged by workgroups that share an L2.  Every tile is visited exactly once whatever the hardware's actual
+// placement; a grid that is not a multiple of 8 walks t, t + grid, ... as before.
+struct TileWalk { int first, step, end; };
+__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
+    TileWalk w;
+    if ((gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7, per = (ntiles + 7) >> 3;
+        w.first = x * per + (blockIdx.x >> 3);
+        w.step = gridDim.x >> 3;
+        w.end = (x + 1) * per < ntiles ? (x + 1) * per : ntiles;
+    } else {
+        w.first = blockIdx.x; w.step = gridDim.x; w.end = ntiles;
+    }
+    return w;
+}
+
 // Persistent form: the grid is 3 workgroups per CU; each loads the 28 KB of B fragments into registers
 // once and then walks its share of the output tiles (tile t, t + gridDim.x, ...), re-filling only the
 // 42 KB input patch per tile.  The co-resident workgroups overlap each other's fill / matrix / store phases.
@@ -117,10 +135,11 @@ __global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchP
         }
     };
 
-    int t = blockIdx.x;
+    const TileWalk tw = tile_walk(p.ntiles);
+    int t = tw.first;
     float vmax = 0.f;
-    if (t < p.ntiles) issue_patch(t);
-    while (t < p.ntiles) {
+    if (t < tw.end) issue_patch(t);
+    while (t < tw.end) {
         const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
         const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
@@ -145,8 +164,8 @@ __global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchP
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, acc1, 0, 0, 0);
         }
         __syncthreads();                                       // every wave is done reading the patch
-        const int tnext = t + gridDim.x;
-        if (tnext < p.ntiles) issue_patch(tnext);              // the refill flies under this tile's stores
+        const int tnext = t + tw.step;
+        if (tnext < tw.end) issue_patch(tnext);                // the refill flies under this tile's stores
 
         // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel), row = 4*(lane>>4) + i (pixel).
         // even lanes store the hi halves of channels (n, n+1), odd lanes the lo halves of (n-1, n): one 4-byte store per value
@@ -229,10 +248,11 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
         }
     };
 
-    int t = blockIdx.x, buf = 0;
+    const TileWalk tw = tile_walk(p.ntiles);
+    int t = tw.first, buf = 0;
     float vmax = 0.f;
     bool stores_counted = false;       // the previous tile issued exactly 8 stores per lane after this tile's patch DMA (interior tile)
-    if (t < p.ntiles) issue_patch(t, 0);
+    if (t < tw.end) issue_patch(t, 0);
     // the wave's 30 weight fragments (30 KB) are fetched behind the first patch's DMA
     half8 wreg[STEPS][2];
 #pragma unroll
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
         wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 0) * 64 + lane) * 16);
         wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 1) * 64 + lane) * 16);
     }
-    while (t < p.ntiles) {
+    while (t < tw.end) {
         const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
         const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
@@ -250,8 +270,8 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
         if (stores_counted) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int tnext = t + gridDim.x;
-        if (tnext < p.ntiles) issue_patch(tnext, buf ^ 1);
+        const int tnext = t + tw.step;
+        if (tnext < tw.end) issue_patch(tnext, buf ^ 1);
 
         const uint8_t* a0 = smem_p2 + buf * PATCH + a_lane;
         f32x4 acc[2];
@@ -375,10 +395,11 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
         }
     };
 
-    int t = blockIdx.x, buf = 0;
+    const TileWalk tw = tile_walk(p.ntiles);
+    int t = tw.first, buf = 0;
     float vmax = 0.f;
     bool stores_counted = false;       // the previous tile issued exactly 16 stores per lane after this tile's patch DMA (interior tile)
-    if (t < p.ntiles) issue_patch(t, 0);
+    if (t < tw.end) issue_patch(t, 0);
     // the wave's 18 weight fragments (18 KB) are fetched behind the first patch's DMA
     half8 wreg[STEPS][2];
 #pragma unroll
@@ -386,7 +407,7 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
         wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 0) * 64 + lane) * 16);
         wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 1) * 64 + lane) * 16);
     }
-    while (t < p.ntiles) {
+    while (t < tw.end) {
         const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
         const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
@@ -396,8 +417,8 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
         if (stores_counted) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int tnext = t + gridDim.x;
-        if (tnext < p.ntiles) issue_patch(tnext, buf ^ 1);
+        const int tnext = t + tw.step;
+        if (tnext < tw.end) issue_patch(tnext, buf ^ 1);
 
         const uint8_t* a0 = smem_p3 + buf * PATCH + a_lane;
         f32x4 acc[4];
