@@ -25,6 +25,12 @@
 
 namespace davo {
 
+#ifdef DAVO_TUNING
+#define CP_DBG(bit_) ((p.dbg & (bit_)) != 0)
+#else
+#define CP_DBG(bit_) false
+#endif
+
 // Tile walk of the persistent patch kernels.  Workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own, so
 // XCD x = id % 8 walks the CONTIGUOUS tile range [x * per, (x + 1) * per): tiles whose patches overlap (the halo is 1.5x - 2x
 // the input) are staged by workgroups that share an L2.  Every tile is visited exactly once whatever the hardware's actual
@@ -41,6 +47,33 @@ __device__ __forceinline__ TileWalk tile_walk(int ntiles) {
         w.first = blockIdx.x; w.step = gridDim.x; w.end = ntiles;
     }
     return w;
+}
+
+// (image, tile row, tile column) of a tile index, advanced by a constant stride without divisions: every wave of a
+// workgroup runs this scalar arithmetic on the CU's one scalar unit, and two runtime divisions per tile and use were a
+// quarter of the loop's scalar instructions.
+struct TileCoord { int n, ty, tx; };
+__device__ __forceinline__ TileCoord tile_coord(int t, int tiles_x, int tiles_y) {
+    TileCoord c;
+    const int per_img = tiles_x * tiles_y;
+    c.n = t / per_img;
+    const int tt = t - c.n * per_img;
+    c.ty = tt / tiles_x;
+    c.tx = tt - c.ty * tiles_x;
+    return c;
+}
+__device__ __forceinline__ TileCoord tile_next(TileCoord c, const TileCoord& s, int tiles_x, int tiles_y) {
+    c.tx += s.tx;
+    if (c.tx >= tiles_x) { c.tx -= tiles_x; ++c.ty; }
+    c.ty += s.ty;
+    if (c.ty >= tiles_y) { c.ty -= tiles_y; ++c.n; }
+    c.n += s.n;
+    return c;
+}
+// source of one 16-byte patch unit: its pixel when inside the image, else the zero line — as two selects, not a branch
+__device__ __forceinline__ const uint8_t* patch_src(bool ok, const uint8_t* img, unsigned off, const uint8_t* zeros) {
+    const unsigned long a = reinterpret_cast<unsigned long>(img) + off, z = reinterpret_cast<unsigned long>(zeros);
+    return reinterpret_cast<const uint8_t*>(ok ? a : z);
 }
 
 // Persistent form: the grid is 3 workgroups per CU; each loads the 28 KB of B fragments into registers
@@ -68,24 +101,25 @@ __global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchP
     // A fragment address of subtile row oy_l: py = 2*oy_l + ky, px = 2*r + 4*h + kq
     const int a_lane = (kq & 1) * ROWB + (r + (kq >> 1)) * 16;
     const uint8_t* a0 = patch + (2 * (2 * wave) * 2) * ROWB + a_lane;
-    const uint8_t* a1 = patch + (2 * (2 * wave + 1) * 2) * ROWB + a_lane;
-    const int tiles_per_img = p.tiles_x * p.tiles_y;
 
     // stage one tile's patch.  !FUSED: LDS-DMA from the packed tensor, one wave-instruction = 64 units
     // = one py, both parities.  FUSED: every thread builds 3-4 patch pixels from the raw inputs
     // (same arithmetic as mask_pack<16>) and writes their hi / lo units.
-    auto issue_patch = [&](int t) {
-        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
-        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+    auto issue_patch = [&](const TileCoord& tc) {
+        const int n = tc.n, ty = tc.ty, tx = tc.tx;
         const int iy_base = ty * TH * 2 - p.pad_t, ix_base = tx * TW * 2 - p.pad_l;
         if constexpr (!FUSED) {
             const uint8_t* xin = p.x + (size_t)n * p.H * p.W * 32;
+            // the lane's column is the same in every piece: its bounds test and byte offset are computed once per tile
+            const int par = lane >> 5, px2 = lane & 31;
+            const int ix = ix_base + 2 * px2 + par;
+            const bool okx = px2 * 2 + par < PW && (unsigned)ix < (unsigned)p.W && !CP_DBG(1);
+            const unsigned offx = (unsigned)ix * 32u;
             for (int k = wave; k < 2 * PH; k += 4) {
-                const int plane = k / PH;
-                const int py = k - plane * PH, par = lane >> 5, px2 = lane & 31;
-                const int iy = iy_base + py, ix = ix_base + 2 * px2 + par;
-                const bool ok = px2 * 2 + par < PW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const uint8_t* src = ok ? xin + ((size_t)iy * p.W + ix) * 32 + plane * 16 : p.zeros;
+                const int plane = k >= PH ? 1 : 0;
+                const int iy = iy_base + k - plane * PH;                    // uniform
+                const bool ok = okx && (unsigned)iy < (unsigned)p.H;
+                const uint8_t* src = patch_src(ok, xin, (unsigned)(iy * p.W) * 32u + offx + plane * 16, p.zeros);
                 __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(patch + k * 1024), 16, 0, 0);
             }
         } else {
@@ -138,24 +172,28 @@ __global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchP
     const TileWalk tw = tile_walk(p.ntiles);
     int t = tw.first;
     float vmax = 0.f;
-    if (t < tw.end) issue_patch(t);
+    TileCoord tc = tile_coord(t, p.tiles_x, p.tiles_y);
+    const TileCoord ts = tile_coord(tw.step, p.tiles_x, p.tiles_y);
+    if (t < tw.end) issue_patch(tc);
     while (t < tw.end) {
-        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
-        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int n = tc.n;
+        const int oy0 = tc.ty * TH, ox0 = tc.tx * TW;
         // explicit drain: when ordinary loads are mixed with LDS-DMA (FUSED fill after the weight DMA)
         // hipcc's own vmcnt bookkeeping does not reliably cover the DMA before the barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        // Matrix phase, software-pipelined by hand (conv_patch_cnv2_h3 has the reasoning): the four fragments of step s+1 are
+        // requested before the six MFMAs of step s are queued, counted waits, alternating accumulator chains.
         f32x4 acc0 = {bv, bv, bv, bv}, acc1 = acc0;
+#ifdef DAVO_CNV1_AUTO
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
             const int ky = step >> 1, h = step & 1;
-            const int aoff = ky * 2 * ROWB + h * 32;           // filter row, +2 units for taps 4..7
+            const int aoff = ky * 2 * ROWB + h * 32;
             const half8 bh = wreg[step][0], bl = wreg[step][1];
             const half8 ah0 = lds_frag(a0 + aoff), al0 = lds_frag(a0 + aoff + PLANE);
-            const half8 ah1 = lds_frag(a1 + aoff), al1 = lds_frag(a1 + aoff + PLANE);
+            const half8 ah1 = lds_frag(a0 + 4 * ROWB + aoff), al1 = lds_frag(a0 + 4 * ROWB + aoff + PLANE);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, acc0, 0, 0, 0);
@@ -163,9 +201,43 @@ __global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchP
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, acc1, 0, 0, 0);
         }
+#else
+        const unsigned a_u32 = lds_u32(a0);                    // subtile row 1 = a0 + 4 ROWB
+        half8 fh[2][2], fl[2][2];                              // [ring slot][subtile row]
+#define C1_RD(dst_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(a_u32), "n"(off_) : "memory")
+#define C1_OFF(S_, G_, PL_) (((S_) >> 1) * 2 * ROWB + ((S_) & 1) * 32 + (G_) * (4 * ROWB) + (PL_) * PLANE)
+#define C1_ISSUE(S_, B_)                                                                           \
+        { C1_RD(fh[B_][0], C1_OFF(S_, 0, 0)); C1_RD(fh[B_][1], C1_OFF(S_, 1, 0));                  \
+          C1_RD(fl[B_][0], C1_OFF(S_, 0, 1)); C1_RD(fl[B_][1], C1_OFF(S_, 1, 1)); }
+#define C1_WAIT(N_, B_) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fh[B_][0]), "+v"(fh[B_][1]), "+v"(fl[B_][0]), "+v"(fl[B_][1]) : "n"(N_))
+#define C1_MM(S_, B_)                                                                              \
+        {   const half8 bh = wreg[S_][0], bl = wreg[S_][1];                                        \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][0], bh, acc0, 0, 0, 0);           \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][1], bh, acc1, 0, 0, 0);           \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][0], bl, acc0, 0, 0, 0);           \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][1], bl, acc1, 0, 0, 0);           \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[B_][0], bh, acc0, 0, 0, 0);           \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[B_][1], bh, acc1, 0, 0, 0); }
+#define C1_STEP(S_)                                                                                \
+        {   if constexpr ((S_) + 1 < STEPS) { C1_ISSUE((S_) + 1, ((S_) + 1) & 1) C1_WAIT(4, (S_) & 1); }   \
+            else { C1_WAIT(0, (S_) & 1); }                                                         \
+            C1_MM(S_, (S_) & 1)                                                                    \
+            __builtin_amdgcn_sched_barrier(0); }
+        C1_ISSUE(0, 0)
+        C1_STEP(0) C1_STEP(1) C1_STEP(2) C1_STEP(3) C1_STEP(4) C1_STEP(5) C1_STEP(6)
+        C1_STEP(7) C1_STEP(8) C1_STEP(9) C1_STEP(10) C1_STEP(11) C1_STEP(12) C1_STEP(13)
+        static_assert(STEPS == 14, "unrolled by hand");
+#undef C1_RD
+#undef C1_OFF
+#undef C1_ISSUE
+#undef C1_WAIT
+#undef C1_MM
+#undef C1_STEP
+#endif
         __syncthreads();                                       // every wave is done reading the patch
         const int tnext = t + tw.step;
-        if (tnext < tw.end) issue_patch(tnext);                // the refill flies under this tile's stores
+        tc = tile_next(tc, ts, p.tiles_x, p.tiles_y);
+        if (tnext < tw.end) issue_patch(tc);                   // the refill flies under this tile's stores
 
         // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel), row = 4*(lane>>4) + i (pixel).
         // even lanes store the hi halves of channels (n, n+1), odd lanes the lo halves of (n-1, n): one 4-byte store per value
@@ -189,7 +261,7 @@ __global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchP
                 const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
                                    ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
                 const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                if (ok) *reinterpret_cast<unsigned*>(orow + i * 64) = __builtin_amdgcn_perm(xn, x, sel);
+                if (ok && !CP_DBG(2)) *reinterpret_cast<unsigned*>(orow + i * 64) = __builtin_amdgcn_perm(xn, x, sel);
             }
         }
         t = tnext;
@@ -226,14 +298,11 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
     // A fragment of group g, step (ky, h), plane pl:  region (pl, kq & 1), patch row 2 (2 g + (r >> 3)) + ky, parity kq >> 1
     // (kx = 2 h + (kq >> 1)), unit (r & 7) + h
     const int a_lane = (kq & 1) * REGION + (kq >> 1) * (PWU * 16) + (r >> 3) * (2 * ROWB) + (r & 7) * 16 + g0 * (4 * ROWB);
-    const int tiles_per_img = p.tiles_x * p.tiles_y;
 
     // this wave stages region `wave` (plane = wave >> 1, channel half = wave & 1): piece k, lane l = linear unit 64 k + l of the region
-    auto issue_patch = [&](int t, int buf) {
-        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
-        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-        const int iy_base = ty * TH * 2 - p.pad_t, ix_base = tx * TW * 2 - p.pad_l;
-        const uint8_t* xin = p.x + (size_t)n * p.H * p.W * 64 + (wave >> 1) * 32 + (wave & 1) * 16;
+    auto issue_patch = [&](const TileCoord& tc, int buf) {
+        const int iy_base = tc.ty * TH * 2 - p.pad_t, ix_base = tc.tx * TW * 2 - p.pad_l;
+        const uint8_t* xin = p.x + (size_t)tc.n * p.H * p.W * 64 + (wave >> 1) * 32 + (wave & 1) * 16;
         uint8_t* dst = smem_p2 + buf * PATCH + wave * REGION;
 #pragma unroll
         for (int k = 0; k < NDMA; ++k) {
@@ -242,8 +311,8 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
             const int rem = L - py * ROW_UNITS;
             const int par = rem >= PWU ? 1 : 0, idx = rem - par * PWU;
             const int iy = iy_base + py, ix = ix_base + 2 * idx + par;
-            const bool ok = py < PH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uint8_t* src = ok ? xin + ((size_t)iy * p.W + ix) * 64 : p.zeros;
+            const bool ok = py < PH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !CP_DBG(1);
+            const uint8_t* src = patch_src(ok, xin, (unsigned)(iy * p.W + ix) * 64u, p.zeros);
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + k * 1024), 16, 0, 0);
         }
     };
@@ -252,7 +321,9 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
     int t = tw.first, buf = 0;
     float vmax = 0.f;
     bool stores_counted = false;       // the previous tile issued exactly 8 stores per lane after this tile's patch DMA (interior tile)
-    if (t < tw.end) issue_patch(t, 0);
+    TileCoord tc = tile_coord(t, p.tiles_x, p.tiles_y);
+    const TileCoord ts = tile_coord(tw.step, p.tiles_x, p.tiles_y);
+    if (t < tw.end) issue_patch(tc, 0);
     // the wave's 30 weight fragments (30 KB) are fetched behind the first patch's DMA
     half8 wreg[STEPS][2];
 #pragma unroll
@@ -261,36 +332,56 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
         wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 1) * 64 + lane) * 16);
     }
     while (t < tw.end) {
-        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
-        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int n = tc.n;
+        const int oy0 = tc.ty * TH, ox0 = tc.tx * TW;
         // this tile's patch has landed (vmcnt counts in issue order and the previous tile's stores are younger than this
         // patch's DMA: they may stay in flight); behind the barrier every wave has also left the previous tile's matrix
         // phase, so the other buffer may be refilled: the next tile's patch flies under this tile's matrix phase and stores
-        if (stores_counted) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (stores_counted && !CP_DBG(2)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int tnext = t + tw.step;
-        if (tnext < tw.end) issue_patch(tnext, buf ^ 1);
+        const TileCoord tcn = tile_next(tc, ts, p.tiles_x, p.tiles_y);
+        if (tnext < tw.end) issue_patch(tcn, buf ^ 1);
 
-        const uint8_t* a0 = smem_p2 + buf * PATCH + a_lane;
+        // Matrix phase, software-pipelined by hand (left to the compiler every step read its fragments, waited for
+        // lgkmcnt(0) and ran three dependent MFMAs per accumulator): the four fragments of step s+1 are requested before the
+        // six MFMAs of step s are queued, the wait is counted (LDS returns in order) and names the fragments it releases, and
+        // the two groups' accumulator chains alternate.  Per accumulator the products still arrive as hi*hi, hi*lo, lo*hi.
+        const unsigned a_u32 = lds_u32(smem_p2 + buf * PATCH + a_lane);
         f32x4 acc[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) acc[g] = f32x4{bv, bv, bv, bv};
-#pragma unroll
-        for (int step = 0; step < STEPS; ++step) {
-            const int ky = step / 3, h = step - 3 * ky;
-            const int aoff = ky * ROWB + h * 16;
-            const half8 bh = wreg[step][0], bl = wreg[step][1];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const half8 ah = lds_frag(a0 + aoff + g * (4 * ROWB));
-                const half8 al = lds_frag(a0 + aoff + g * (4 * ROWB) + 2 * REGION);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[g], 0, 0, 0);
-            }
-        }
+        half8 fh[2][2], fl[2][2];                              // [ring slot][group]
+#define C2_RD(dst_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(a_u32), "n"(off_) : "memory")
+#define C2_OFF(S_, G_, PL_) (((S_) / 3) * ROWB + ((S_) % 3) * 16 + (G_) * (4 * ROWB) + (PL_) * (2 * REGION))
+#define C2_ISSUE(S_, B_)                                                                           \
+        { C2_RD(fh[B_][0], C2_OFF(S_, 0, 0)); C2_RD(fh[B_][1], C2_OFF(S_, 1, 0));                  \
+          C2_RD(fl[B_][0], C2_OFF(S_, 0, 1)); C2_RD(fl[B_][1], C2_OFF(S_, 1, 1)); }
+#define C2_WAIT(N_, B_) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fh[B_][0]), "+v"(fh[B_][1]), "+v"(fl[B_][0]), "+v"(fl[B_][1]) : "n"(N_))
+#define C2_MM(S_, B_)                                                                              \
+        {   const half8 bh = wreg[S_][0], bl = wreg[S_][1];                                        \
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][0], bh, acc[0], 0, 0, 0);       \
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][1], bh, acc[1], 0, 0, 0);       \
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][0], bl, acc[0], 0, 0, 0);       \
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][1], bl, acc[1], 0, 0, 0);       \
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[B_][0], bh, acc[0], 0, 0, 0);       \
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[B_][1], bh, acc[1], 0, 0, 0); }
+#define C2_STEP(S_)                                                                                \
+        {   if constexpr ((S_) + 1 < STEPS) { C2_ISSUE((S_) + 1, ((S_) + 1) & 1) C2_WAIT(4, (S_) & 1); }   \
+            else { C2_WAIT(0, (S_) & 1); }                                                         \
+            C2_MM(S_, (S_) & 1)                                                                    \
+            __builtin_amdgcn_sched_barrier(0); }
+        C2_ISSUE(0, 0)
+        C2_STEP(0) C2_STEP(1) C2_STEP(2) C2_STEP(3) C2_STEP(4) C2_STEP(5) C2_STEP(6) C2_STEP(7)
+        C2_STEP(8) C2_STEP(9) C2_STEP(10) C2_STEP(11) C2_STEP(12) C2_STEP(13) C2_STEP(14)
+        static_assert(STEPS == 15, "unrolled by hand");
+#undef C2_RD
+#undef C2_OFF
+#undef C2_ISSUE
+#undef C2_WAIT
+#undef C2_MM
+#undef C2_STEP
 
         // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel 16 ng + r), row = 4 kq + i = pixel of the group:
         // output row 2 g + (kq >> 1), column 4 (kq & 1) + i.  Even lanes store the hi halves of channels (c, c+1), odd lanes the
@@ -316,7 +407,7 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
                     const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
                                        ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
                     const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                    *reinterpret_cast<unsigned*>(orow + i * 128) = __builtin_amdgcn_perm(xn, x, sel);
+                    if (!CP_DBG(2)) *reinterpret_cast<unsigned*>(orow + i * 128) = __builtin_amdgcn_perm(xn, x, sel);
                 }
             }
         } else {
@@ -342,6 +433,7 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
             }
         }
         t = tnext;
+        tc = tcn;
         buf ^= 1;
     }
     if (p.range) {
@@ -371,14 +463,11 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
     // A fragment of group g, tap (ky, kx), plane pl: region (pl, kq), patch row (4 (g >> 1) + (g & 1) + 2 (r >> 3)) + 2 ky,
     // pixel (r & 7) + 2 kx
     const int a_lane = kq * REGION + (r >> 3) * (2 * ROWB) + (r & 7) * 16;
-    const int tiles_per_img = p.tiles_x * p.tiles_y;
 
     // piece k, lane l = linear 16-byte unit 64 k + l of the patch [region][row][pixel]; the waves take pieces k = wave, wave + 4, ...
-    auto issue_patch = [&](int t, int buf) {
-        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
-        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-        const int iy_base = ty * TH - p.pad_t, ix_base = tx * TW - p.pad_l;
-        const uint8_t* xin = p.x + (size_t)n * p.H * p.W * 128;
+    auto issue_patch = [&](const TileCoord& tc, int buf) {
+        const int iy_base = tc.ty * TH - p.pad_t, ix_base = tc.tx * TW - p.pad_l;
+        const uint8_t* xin = p.x + (size_t)tc.n * p.H * p.W * 128;
         uint8_t* dst = smem_p3 + buf * PATCH;
 #pragma unroll
         for (int kk = 0; kk < (NDMA + 3) / 4; ++kk) {
@@ -388,8 +477,8 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
                 const int reg = L / (PH * PW), rem = L - reg * (PH * PW);
                 const int py = rem / PW, px = rem - py * PW;
                 const int iy = iy_base + py, ix = ix_base + px;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const uint8_t* src = ok ? xin + ((size_t)iy * p.W + ix) * 128 + (reg >> 2) * 64 + (reg & 3) * 16 : p.zeros;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !CP_DBG(1);
+                const uint8_t* src = patch_src(ok, xin, (unsigned)(iy * p.W + ix) * 128u + (reg >> 2) * 64 + (reg & 3) * 16, p.zeros);
                 __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + k * 1024), 16, 0, 0);
             }
         }
@@ -399,7 +488,9 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
     int t = tw.first, buf = 0;
     float vmax = 0.f;
     bool stores_counted = false;       // the previous tile issued exactly 16 stores per lane after this tile's patch DMA (interior tile)
-    if (t < tw.end) issue_patch(t, 0);
+    TileCoord tc = tile_coord(t, p.tiles_x, p.tiles_y);
+    const TileCoord ts = tile_coord(tw.step, p.tiles_x, p.tiles_y);
+    if (t < tw.end) issue_patch(tc, 0);
     // the wave's 18 weight fragments (18 KB) are fetched behind the first patch's DMA
     half8 wreg[STEPS][2];
 #pragma unroll
@@ -408,38 +499,57 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
         wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 1) * 64 + lane) * 16);
     }
     while (t < tw.end) {
-        const int n = t / tiles_per_img, tt = t - n * tiles_per_img;
-        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int n = tc.n;
+        const int oy0 = tc.ty * TH, ox0 = tc.tx * TW;
         // this tile's patch has landed (the previous tile's stores are younger than its DMA and may stay in flight);
         // behind the barrier every wave has also left the previous tile's matrix phase, so the other buffer may be
         // refilled: the next tile's patch flies under this tile's matrix phase and stores
-        if (stores_counted) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (stores_counted && !CP_DBG(2)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int tnext = t + tw.step;
-        if (tnext < tw.end) issue_patch(tnext, buf ^ 1);
+        const TileCoord tcn = tile_next(tc, ts, p.tiles_x, p.tiles_y);
+        if (tnext < tw.end) issue_patch(tcn, buf ^ 1);
 
-        const uint8_t* a0 = smem_p3 + buf * PATCH + a_lane;
+        // Matrix phase, software-pipelined by hand as in conv_patch_cnv2_h3, in half-steps of two pixel groups: the four
+        // fragments of half-step h+1 are requested before the six MFMAs of half-step h are queued (a ring of 2 x 4 fragment
+        // registers: three waves per SIMD need <= 168 registers, 72 of them hold weights).
+        const unsigned a_u32 = lds_u32(smem_p3 + buf * PATCH + a_lane);
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{bv, bv, bv, bv};
-#pragma unroll
-        for (int step = 0; step < STEPS; ++step) {
-            const int ky = step / 3, kx = step - 3 * ky;
-            const int aoff = ky * (RATE * ROWB) + kx * (RATE * 16);
-            const half8 bh = wreg[step][0], bl = wreg[step][1];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int goff = (4 * (g >> 1) + (g & 1)) * ROWB;
-                const half8 ah = lds_frag(a0 + aoff + goff);
-                const half8 al = lds_frag(a0 + aoff + goff + 4 * REGION);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[g], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);                 // fragments of at most one step ahead: three waves per SIMD need <= 168 registers
-        }
+        half8 fh[2][2], fl[2][2];                              // [ring slot][group of the pair]
+#define C3_RD(dst_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(a_u32), "n"(off_) : "memory")
+        // half-step H_ = (step H_ >> 1, group pair H_ & 1): groups 2 (H_ & 1) and 2 (H_ & 1) + 1 = tile rows 4 (H_ & 1) + {0,2} / {1,3}
+#define C3_OFF(H_, G_, PL_) ((((H_) >> 1) / 3) * (RATE * ROWB) + (((H_) >> 1) % 3) * (RATE * 16) + (4 * ((H_) & 1) + (G_)) * ROWB + (PL_) * (4 * REGION))
+#define C3_ISSUE(H_, B_)                                                                           \
+        { C3_RD(fh[B_][0], C3_OFF(H_, 0, 0)); C3_RD(fh[B_][1], C3_OFF(H_, 1, 0));                  \
+          C3_RD(fl[B_][0], C3_OFF(H_, 0, 1)); C3_RD(fl[B_][1], C3_OFF(H_, 1, 1)); }
+#define C3_WAIT(N_, B_) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fh[B_][0]), "+v"(fh[B_][1]), "+v"(fl[B_][0]), "+v"(fl[B_][1]) : "n"(N_))
+#define C3_MM(H_, B_)                                                                              \
+        {   const half8 bh = wreg[(H_) >> 1][0], bl = wreg[(H_) >> 1][1];                          \
+            constexpr int g_ = 2 * ((H_) & 1);                                                     \
+            acc[g_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][0], bh, acc[g_], 0, 0, 0);     \
+            acc[g_ + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][1], bh, acc[g_ + 1], 0, 0, 0); \
+            acc[g_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][0], bl, acc[g_], 0, 0, 0);     \
+            acc[g_ + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][1], bl, acc[g_ + 1], 0, 0, 0); \
+            acc[g_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[B_][0], bh, acc[g_], 0, 0, 0);     \
+            acc[g_ + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[B_][1], bh, acc[g_ + 1], 0, 0, 0); }
+#define C3_HALF(H_)                                                                                \
+        {   if constexpr ((H_) + 1 < 2 * STEPS) { C3_ISSUE((H_) + 1, ((H_) + 1) & 1) C3_WAIT(4, (H_) & 1); }   \
+            else { C3_WAIT(0, (H_) & 1); }                                                         \
+            C3_MM(H_, (H_) & 1)                                                                    \
+            __builtin_amdgcn_sched_barrier(0); }
+        C3_ISSUE(0, 0)
+        C3_HALF(0) C3_HALF(1) C3_HALF(2) C3_HALF(3) C3_HALF(4) C3_HALF(5) C3_HALF(6) C3_HALF(7) C3_HALF(8)
+        C3_HALF(9) C3_HALF(10) C3_HALF(11) C3_HALF(12) C3_HALF(13) C3_HALF(14) C3_HALF(15) C3_HALF(16) C3_HALF(17)
+        static_assert(STEPS == 9, "unrolled by hand");
+#undef C3_RD
+#undef C3_OFF
+#undef C3_ISSUE
+#undef C3_WAIT
+#undef C3_MM
+#undef C3_HALF
 
         // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel 16 wave + r), row = 4 kq + i = pixel of the group:
         // output row 4 (g >> 1) + (g & 1) + 2 (kq >> 1), column 4 (kq & 1) + i.  The 64 output channels are two blocks of
@@ -465,7 +575,7 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
                     const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
                                        ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
                     const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                    *reinterpret_cast<unsigned*>(orow + i * 256) = __builtin_amdgcn_perm(xn, x, sel);
+                    if (!CP_DBG(2)) *reinterpret_cast<unsigned*>(orow + i * 256) = __builtin_amdgcn_perm(xn, x, sel);
                 }
             }
         } else {
@@ -491,6 +601,7 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
             }
         }
         t = tnext;
+        tc = tcn;
         buf ^= 1;
     }
     if (p.range) {
@@ -499,5 +610,7 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
         if (lane == 0 && __float_as_uint(vmax) > __atomic_load_n(p.range, __ATOMIC_RELAXED)) atomicMax(p.range, __float_as_uint(vmax));
     }
 }
+
+#undef CP_DBG
 
 }  // namespace davo

@@ -223,6 +223,7 @@ int run_cnv1_patch(davo_ctx* c, bool fused, const void* d_img, const void* d_flo
     p.seg = static_cast<const float*>(d_seg); p.tab = c->d_tab; p.v = c->v;
     c->last_plan[0][0] = ((NB * Ho * Wo + 127) / 128) * 1000 + 99; c->last_plan[0][1] = 0;
     const int nblk = p.ntiles < 3 * c->ncu ? p.ntiles : 3 * c->ncu;   // 3 workgroups per CU, each walks its tiles
+    if (const char* e = tuning_env("DAVO_PDBG")) p.dbg = atoi(e);      // tuning build only
     ProfScope ps(c, "cnv1");
     HIP_TRY(c, launch_cnv1_patch(fused, p, nblk, c->stream));
     return DAVO_OK;
@@ -245,6 +246,7 @@ int run_cnv2_patch(davo_ctx* c, const void* x, void* y, int NB) {
     p.ntiles = NB * p.tiles_x * p.tiles_y;
     c->last_plan[1][0] = ((NB * Ho * Wo + 127) / 128) * 1000 + 98; c->last_plan[1][1] = 0;
     const int nblk = p.ntiles < 2 * c->ncu ? p.ntiles : 2 * c->ncu;   // 2 workgroups per CU (120 weight registers per lane), each walks its tiles
+    if (const char* e = tuning_env("DAVO_PDBG")) p.dbg = atoi(e);      // tuning build only
     ProfScope ps(c, "cnv2");
     HIP_TRY(c, launch_cnv2_patch(p, nblk, c->stream));
     return DAVO_OK;
@@ -264,6 +266,7 @@ int run_cnv3_patch(davo_ctx* c, const void* x, void* y, int NB) {
     p.ntiles = NB * p.tiles_x * p.tiles_y;
     c->last_plan[2][0] = ((NB * p.Ho * p.Wo + 127) / 128) * 1000 + 97; c->last_plan[2][1] = 0;
     const int nblk = p.ntiles < 3 * c->ncu ? p.ntiles : 3 * c->ncu;   // 3 workgroups per CU, each walks its tiles
+    if (const char* e = tuning_env("DAVO_PDBG")) p.dbg = atoi(e);      // tuning build only
     ProfScope ps(c, "cnv3");
     HIP_TRY(c, launch_cnv3_patch(p, nblk, c->stream));
     return DAVO_OK;

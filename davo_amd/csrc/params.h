@@ -190,6 +190,7 @@ struct ConvPatchParams {
     const float* seg;       // [B][3][H][W][1]
     const float* tab;       // [B][3][19] attention tables (se_excite)
     Variant v;
+    int dbg;                // measurement only (-DDAVO_TUNING, DAVO_PDBG): 1 = every patch load reads the zero line, 2 = no stores
 };
 
 }  // namespace davo
