@@ -119,6 +119,9 @@ void conv_igemm_h3(ConvParamsH p) {
         if (slot_i >= 1 && slot_i < nslot_ && blockIdx.y == 0)
             for (int i = 0; i < slot_i * ((p.dbg >> 16) & 0xff); ++i) __builtin_amdgcn_s_sleep(127);
     }
+    // 16384 / 32768: the same with "second slot" = odd workgroup of its XCD / odd workgroup id (first 512 workgroups)
+    if (H3_DBG(16384 | 32768) && blockIdx.x < 512 && blockIdx.y == 0 && (H3_DBG(16384) ? ((blockIdx.x >> 3) & 1) : (blockIdx.x & 1)))
+        for (int i = 0; i < ((p.dbg >> 16) & 0xff); ++i) __builtin_amdgcn_s_sleep(127);
 #endif
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int ntile = tile % p.ntiles_n, mtile = p.mtile0 + tile / p.ntiles_n;

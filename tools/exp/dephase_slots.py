@@ -19,9 +19,12 @@ img, flow, seg = synth.make_inputs(8, H, W)
 img, flow, seg = np.tile(img, (4, 1, 1, 1)), np.tile(flow, (4, 1, 1, 1, 1)), np.tile(seg, (4, 1, 1, 1, 1))
 d = (e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48))
 arms = [("base", 0)]
-for slots in (2, 3):
-    for n in (1, 2, 3, 4):
+for slots in (2,):
+    for n in (2, 4):
         arms.append(("%d slots, +%d us/slot" % (slots, 4 * n), 8192 | (n << 16) | (slots << 24)))
+for bit, nm in ((16384, "odd in XCD"), (32768, "odd id")):
+    for n in (1, 2, 3, 4, 6):
+        arms.append(("%s +%d us" % (nm, 4 * n), bit | (n << 16)))
 res = {a[0]: {} for a in arms}
 for rnd in range(3):
     for name, dbg in arms:
