@@ -76,6 +76,22 @@ __device__ __forceinline__ const uint8_t* patch_src(bool ok, const uint8_t* img,
     return reinterpret_cast<const uint8_t*>(ok ? a : z);
 }
 
+// Two activations -> their stored form: v = min(max(x * scale, 0), 65504) (ReLU; 65504 = the fp16 range),
+// H = {fp16(v0), fp16(v1)}, L = {fp16(v0 - H0), fp16(v1 - H1)}; vm collects max v before the upper clamp (range monitor).
+// On 2-vectors so that hipcc emits the packed forms (v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32): same roundings.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_relu(float x0, float x1, float scale, float& vm, unsigned& H, unsigned& L) {
+    f32x2 v = f32x2{x0, x1} * scale;
+    v = __builtin_elementwise_max(v, f32x2{0.f, 0.f});
+    vm = fmaxf(vm, fmaxf(v[0], v[1]));
+    v = __builtin_elementwise_min(v, f32x2{65504.f, 65504.f});
+    const half2v hi = __builtin_convertvector(v, half2v);
+    const half2v lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), half2v);
+    H = __builtin_bit_cast(unsigned, hi);
+    L = __builtin_bit_cast(unsigned, lo);
+}
+
 // Persistent form: the grid is 3 workgroups per CU; each loads the 28 KB of B fragments into registers
 // once and then walks its share of the output tiles (tile t, t + gridDim.x, ...), re-filling only the
 // 42 KB input patch per tile.  The co-resident workgroups overlap each other's fill / matrix / store phases.
@@ -95,6 +111,10 @@ __global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchP
         wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)(st * 2 + 0) * 64 + lane) * 16);
         wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)(st * 2 + 1) * 64 + lane) * 16);
     }
+    // the weight loads are waited for HERE, with the builtin the compiler's wait-count pass understands: an inline-asm wait is
+    // opaque to it, and it would otherwise put its own vmcnt(0) at the weights' first use inside the tile loop - behind the
+    // next patch's DMA, serialising the prefetch (tools/check_isa.py guards the loops of all three kernels)
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
 
     const int r = lane & 15, kq = lane >> 4;
     const float bv = p.bias[r] * p.bias_scale;                 // C/D layout: col = lane & 15
@@ -294,8 +314,13 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ng = wave & 1, g0 = 2 * (wave >> 1);
     const int r = lane & 15, kq = lane >> 4;
-    const float bv = p.bias[16 * ng + r] * p.bias_scale;       // C/D layout: col = lane & 15 = channel
-    // A fragment of group g, step (ky, h), plane pl:  region (pl, kq & 1), patch row 2 (2 g + (r >> 3)) + ky, parity kq >> 1
+    // The weights are the MFMA's A operand, the pixels its B operand: C[channel][pixel], so a lane's accumulator quad is
+    // FOUR CONSECUTIVE CHANNELS 16 ng + 4 kq .. +3 of pixel r of the group, and the split store is one 8-byte store of hi
+    // halves and one of lo halves per quad, with no lane exchange (half the stores and less than half the epilogue
+    // arithmetic of the pixel-major form; same products in the same order per accumulator).
+    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + 16 * ng + 4 * kq);
+    const f32x4 bv4 = {b4.x * p.bias_scale, b4.y * p.bias_scale, b4.z * p.bias_scale, b4.w * p.bias_scale};
+    // pixel fragment of group g, step (ky, h), plane pl:  region (pl, kq & 1), patch row 2 (2 g + (r >> 3)) + ky, parity kq >> 1
     // (kx = 2 h + (kq >> 1)), unit (r & 7) + h
     const int a_lane = (kq & 1) * REGION + (kq >> 1) * (PWU * 16) + (r >> 3) * (2 * ROWB) + (r & 7) * 16 + g0 * (4 * ROWB);
 
@@ -320,7 +345,7 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
     const TileWalk tw = tile_walk(p.ntiles);
     int t = tw.first, buf = 0;
     float vmax = 0.f;
-    bool stores_counted = false;       // the previous tile issued exactly 8 stores per lane after this tile's patch DMA (interior tile)
+    bool stores_counted = false;       // the previous tile issued exactly 4 stores per lane after this tile's patch DMA (interior tile)
     TileCoord tc = tile_coord(t, p.tiles_x, p.tiles_y);
     const TileCoord ts = tile_coord(tw.step, p.tiles_x, p.tiles_y);
     if (t < tw.end) issue_patch(tc, 0);
@@ -331,13 +356,14 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
         wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 0) * 64 + lane) * 16);
         wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 2 + ng) * 2 + 1) * 64 + lane) * 16);
     }
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));         // see conv_patch_cnv1_h3: no compiler-placed vmcnt wait inside the tile loop
     while (t < tw.end) {
         const int n = tc.n;
         const int oy0 = tc.ty * TH, ox0 = tc.tx * TW;
         // this tile's patch has landed (vmcnt counts in issue order and the previous tile's stores are younger than this
         // patch's DMA: they may stay in flight); behind the barrier every wave has also left the previous tile's matrix
         // phase, so the other buffer may be refilled: the next tile's patch flies under this tile's matrix phase and stores
-        if (stores_counted && !CP_DBG(2)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (stores_counted && !CP_DBG(2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int tnext = t + tw.step;
@@ -351,7 +377,7 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
         const unsigned a_u32 = lds_u32(smem_p2 + buf * PATCH + a_lane);
         f32x4 acc[2];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) acc[g] = f32x4{bv, bv, bv, bv};
+        for (int g = 0; g < 2; ++g) acc[g] = bv4;
         half8 fh[2][2], fl[2][2];                              // [ring slot][group]
 #define C2_RD(dst_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(a_u32), "n"(off_) : "memory")
 #define C2_OFF(S_, G_, PL_) (((S_) / 3) * ROWB + ((S_) % 3) * 16 + (G_) * (4 * ROWB) + (PL_) * (2 * REGION))
@@ -361,12 +387,12 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
 #define C2_WAIT(N_, B_) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fh[B_][0]), "+v"(fh[B_][1]), "+v"(fl[B_][0]), "+v"(fl[B_][1]) : "n"(N_))
 #define C2_MM(S_, B_)                                                                              \
         {   const half8 bh = wreg[S_][0], bl = wreg[S_][1];                                        \
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][0], bh, acc[0], 0, 0, 0);       \
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][1], bh, acc[1], 0, 0, 0);       \
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][0], bl, acc[0], 0, 0, 0);       \
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[B_][1], bl, acc[1], 0, 0, 0);       \
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[B_][0], bh, acc[0], 0, 0, 0);       \
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[B_][1], bh, acc[1], 0, 0, 0); }
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, fh[B_][0], acc[0], 0, 0, 0);       \
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, fh[B_][1], acc[1], 0, 0, 0);       \
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, fh[B_][0], acc[0], 0, 0, 0);       \
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, fh[B_][1], acc[1], 0, 0, 0);       \
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, fl[B_][0], acc[0], 0, 0, 0);       \
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, fl[B_][1], acc[1], 0, 0, 0); }
 #define C2_STEP(S_)                                                                                \
         {   if constexpr ((S_) + 1 < STEPS) { C2_ISSUE((S_) + 1, ((S_) + 1) & 1) C2_WAIT(4, (S_) & 1); }   \
             else { C2_WAIT(0, (S_) & 1); }                                                         \
@@ -383,52 +409,26 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
 #undef C2_MM
 #undef C2_STEP
 
-        // ---- epilogue: C/D of 16x16x32: col = lane & 15 (channel 16 ng + r), row = 4 kq + i = pixel of the group:
-        // output row 2 g + (kq >> 1), column 4 (kq & 1) + i.  Even lanes store the hi halves of channels (c, c+1), odd lanes the
-        // lo halves of (c-1, c): one 4-byte store per value (as conv_patch_cnv1_h3)
-        const bool odd = r & 1;
-        const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-        const int cfull = 16 * ng + r;
-        const int choff = odd ? 64 + (cfull - 1) * 2 : cfull * 2;
+        // ---- epilogue: C/D of 16x16x32 with the weights as A: row = 4 kq + i = channel 16 ng + 4 kq + i, col = lane & 15 =
+        // pixel r of the group: output row 2 g + (r >> 3), column r & 7.  A pixel is [32 hi | 32 lo] halves: the quad's hi halves
+        // are 8 bytes at 2 c0, its lo halves 8 bytes at 64 + 2 c0.
         const bool interior = oy0 + TH <= p.Ho && ox0 + TW <= p.Wo;   // uniform; every tile of a 128x416 / 256x832 frame
         stores_counted = interior;
-        if (interior) {
+        const int c0 = 16 * ng + 4 * kq;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int oy = oy0 + 2 * (g0 + g) + (kq >> 1);
-                uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0 + 4 * (kq & 1)) * 128 + choff;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = fmaxf(acc[g][i] * p.out_scale, 0.f);
-                    vmax = fmaxf(vmax, v);
-                    v = fminf(v, 65504.f);
-                    const _Float16 hi = (_Float16)v;
-                    const _Float16 lo = (_Float16)(v - (float)hi);
-                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
-                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                    if (!CP_DBG(2)) *reinterpret_cast<unsigned*>(orow + i * 128) = __builtin_amdgcn_perm(xn, x, sel);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int oy = oy0 + 2 * (g0 + g) + (kq >> 1);
-                if (oy >= p.Ho) continue;
-                const int oxb = ox0 + 4 * (kq & 1);
-                uint8_t* __restrict__ orow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + oxb) * 128 + choff;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = fmaxf(acc[g][i] * p.out_scale, 0.f);
-                    const bool ok = oxb + i < p.Wo;
-                    if (ok) vmax = fmaxf(vmax, v);
-                    v = fminf(v, 65504.f);
-                    const _Float16 hi = (_Float16)v;
-                    const _Float16 lo = (_Float16)(v - (float)hi);
-                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |
-                                       ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
-                    if (ok) *reinterpret_cast<unsigned*>(orow + i * 128) = __builtin_amdgcn_perm(xn, x, sel);
+        for (int g = 0; g < 2; ++g) {
+            const int oy = oy0 + 2 * (g0 + g) + (r >> 3), ox = ox0 + (r & 7);
+            const bool ok = interior || (oy < p.Ho && ox < p.Wo);
+            uint8_t* __restrict__ o = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * 128 + c0 * 2;
+            float vm = 0.f;
+            uint2 hw, lw;
+            split_pair_relu(acc[g][0], acc[g][1], p.out_scale, vm, hw.x, lw.x);
+            split_pair_relu(acc[g][2], acc[g][3], p.out_scale, vm, hw.y, lw.y);
+            if (ok) {
+                vmax = fmaxf(vmax, vm);
+                if (!CP_DBG(2)) {
+                    *reinterpret_cast<uint2*>(o) = hw;
+                    *reinterpret_cast<uint2*>(o + 64) = lw;
                 }
             }
         }
@@ -498,6 +498,7 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
         wreg[st][0] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 0) * 64 + lane) * 16);
         wreg[st][1] = *reinterpret_cast<const half8*>(p.w + ((size_t)((st * 4 + wave) * 2 + 1) * 64 + lane) * 16);
     }
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));         // see conv_patch_cnv1_h3: no compiler-placed vmcnt wait inside the tile loop
     while (t < tw.end) {
         const int n = tc.n;
         const int oy0 = tc.ty * TH, ox0 = tc.tx * TW;

@@ -16,9 +16,56 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FORBIDDEN = re.compile(r"^\s*(s_load_|s_buffer_load|s_scratch_load|ds_bpermute|ds_permute|ds_swizzle|ds_write|ds_add|ds_read_(?!b128)|s_sendmsg|s_memtime|s_memrealtime|flat_)")
 
 
-def compile_to_asm(out):
+def compile_to_asm(out, unit="launch_h3.hip"):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                           "-o", out, os.path.join(ROOT, "davo_amd", "csrc", "launch_h3.hip")], stderr=subprocess.DEVNULL)
+                           "-o", out, os.path.join(ROOT, "davo_amd", "csrc", unit)], stderr=subprocess.DEVNULL)
+
+
+def check_patch_loops(path):
+    """The persistent patch kernels (csrc/conv_patch_h3.h) prefetch the next tile's patch by LDS-DMA while a tile computes,
+    and wait for it with hand-written, counted `s_waitcnt vmcnt(n)` (inline asm).  A vmcnt wait that the COMPILER adds inside
+    the tile loop (e.g. for weight registers it cannot prove loaded: an inline-asm wait is opaque to its wait-count pass)
+    sits behind that DMA and silently serialises the prefetch.  Guard: inside every loop of a conv_patch kernel that holds
+    an s_barrier, each vmcnt wait must be an inline-asm one."""
+    problems, n_kernels = [], 0
+    lines = open(path).read().splitlines()
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^(_ZN4davo18conv_patch_cnv\w+):", lines[i])
+        if not m:
+            i += 1
+            continue
+        name, j = m.group(1), i + 1
+        while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+            j += 1
+        body = lines[i:j]
+        n_kernels += 1
+        if "ILb1E" in name:
+            i = j
+            continue                                    # the FUSED cnv1 variant fills its patch through registers: ordinary loads
+        # loop membership of every line from the compiler's block annotations ("=>This ... Loop Header", "in Loop: Header=BBx_y")
+        member, cur = [], None
+        for l in body:
+            mm = re.match(r"^(?:\.L(BB\d+_\d+):|; %bb\.\d+:)(.*)$", l)
+            if mm:
+                note = mm.group(2)
+                if "Loop Header" in note and "=>" in note:
+                    cur = mm.group(1)
+                else:
+                    hh = re.search(r"in Loop: Header=(BB\d+_\d+)", note)
+                    cur = hh.group(1) if hh else None
+            member.append(cur)
+        tile_headers = {member[k] for k, l in enumerate(body) if member[k] and l.strip().startswith("s_barrier")}
+        if not tile_headers:
+            problems.append("%s: no tile loop with a barrier found" % name)
+        for k, l in enumerate(body):
+            if not l.strip().startswith("s_waitcnt") or "vmcnt" not in l or member[k] not in tile_headers:
+                continue
+            prev = next((body[q].strip() for q in range(k - 1, -1, -1) if body[q].strip()), "")
+            if not prev.startswith(";;#ASMSTART"):
+                problems.append("%s: compiler-placed `%s' inside the tile loop" % (name, l.strip()))
+        i = j
+    return n_kernels, problems
 
 
 def check(path):
@@ -70,7 +117,16 @@ def main():
     print("%d 16x16x32 kernels, %d chunk bodies checked, %d problem(s)" % (nk, nc, len(problems)))
     for p in problems[:20]:
         print("  " + p)
-    return 1 if problems or nk == 0 or nc == 0 else 0
+    npk, pprob = 1, []
+    if len(sys.argv) <= 1:
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "launch_misc.s")
+            compile_to_asm(out, "launch_misc.hip")
+            npk, pprob = check_patch_loops(out)
+        print("%d patch kernels checked, %d problem(s)" % (npk, len(pprob)))
+        for p in pprob[:20]:
+            print("  " + p)
+    return 1 if problems or pprob or nk == 0 or nc == 0 or npk == 0 else 0
 
 
 if __name__ == "__main__":
