@@ -90,6 +90,8 @@ def parse_args():
                     help="skip the extra 2-in-flight throughput measurement (used for the rocprofv3 passes, so that "
                          "per-kernel statistics are not mixed with overlapped launches)")
     ap.add_argument("--no-f32", action="store_true", help="skip the strict-float32 leg (roofline_f32)")
+    ap.add_argument("--profile-stride", type=int, default=0,
+                    help="HIP events around the dominant kernel of every n-th timed step (default: 4 when steps >= 40, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="triplets per CPU-baseline pass")
     return ap.parse_args()
@@ -163,7 +165,9 @@ def main():
 
     # timed region: K steps; only the dominant kernel (main cnv6 launch) is bracketed by HIP events
     # on the launch stream, so the event records do not perturb the other launches
+    # (every 4th step: an event pair puts two ~6 us bubbles around the launch it brackets - 1 % of the step if every launch is timed)
     eng.profile(2)
+    eng.set_option("profile_stride", args.profile_stride or (4 if args.steps >= 40 else 1))
     eng.profile_reset()
     elapsed_max = timed(lambda k: [eng.forward_device(B, *sets[i % nset]) for i in range(k)], args.steps)
     dominant = eng.profile_entries()
@@ -219,7 +223,7 @@ def main():
         return {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                "peak_note": peak_note, "avg_launch_ms": round(avg6, 4), "flops_per_launch": flops_main,
+                "peak_note": peak_note, "avg_launch_ms": round(avg6, 4), "launches_timed": n6, "flops_per_launch": flops_main,
                 "launch_plan": "cnv6 as %s (mtiles of 128 rows, N tile)" % plan}
 
     # the reference's own arithmetic (float32, nets/posenn.py:205-215 slim.conv2d) as a first-class result:
@@ -230,6 +234,7 @@ def main():
         for _ in range(max(2, args.warmup // 10)):
             eng.forward_device(B, d_img, d_flow, d_seg, d_pose)
         eng.profile(2)
+        eng.set_option("profile_stride", args.profile_stride or (4 if args.steps >= 40 else 1))
         eng.profile_reset()
         f32_elapsed = timed(lambda k: [eng.forward_device(B, d_img, d_flow, d_seg, d_pose) for _ in range(k)], args.steps)
         dom32 = eng.profile_entries()

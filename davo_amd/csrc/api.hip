@@ -458,6 +458,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
         int rc = rebuild_slot_streams(c, c->inflight);
         if (rc) return rc;
     }
+    else if (k == "profile_stride") { if (value < 1) return fail(c, DAVO_ERR_INVALID, "profile_stride must be >= 1"); c->prof_stride = value; c->prof_tick = 0; }
     else if (k == "host_chunk") { if (value < 0) return fail(c, DAVO_ERR_INVALID, "host_chunk must be >= 0"); c->host_chunk = value; }
     else return fail(c, DAVO_ERR_INVALID, "unknown option `%s'", key);
     return DAVO_OK;

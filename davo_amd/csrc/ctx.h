@@ -120,6 +120,8 @@ struct davo_ctx {
     // profiling
     bool prof = false;
     bool prof_dominant_only = false;           // profile mode 2: bracket only the main cnv6 launch
+    int prof_stride = 1, prof_tick = 0;        // ... of every prof_stride-th batch (davo_set_option "profile_stride"): an event pair
+                                               // costs two ~6 us bubbles around the launch it brackets
     std::vector<davo::ProfEntry> prof_entries;
     std::vector<hipEvent_t> event_pool;
     // multi-GPU (comm.hip)

@@ -19,7 +19,10 @@ namespace davo {
 // ---- profiling ------------------------------------------------------------------------------------
 ProfScope::ProfScope(davo_ctx* ctx, const char* name) : c(ctx) {
     if (!c->prof) return;
-    if (c->prof_dominant_only && strcmp(name, "cnv6") != 0) return;
+    if (c->prof_dominant_only) {
+        if (strcmp(name, "cnv6") != 0) return;
+        if (c->prof_tick++ % c->prof_stride != 0) return;
+    }
     for (auto& pe : c->prof_entries)
         if (pe.name == name) { e = &pe; break; }
     if (!e) {

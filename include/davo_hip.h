@@ -161,6 +161,8 @@ int davo_set_activation_shifts(davo_ctx* ctx, const int* shifts);
  *   "force_tile" (test hook, default -1 = the launch planner decides): tile id of csrc/plan.h (0 128x32, 1 256x64,
  *       2 256x128, 3 128x256, 4 128x128, 5 256x256, 6 208x256); every f16x3 layer the tile fits is issued as one
  *       launch of that shape.  Poses do not depend on it beyond float32 rounding of the fused pose head's sums.
+ *   "profile_stride" (default 1): with davo_profile_enable(ctx, 2) (only the dominant kernel bracketed by HIP events) the
+ *       events go around every n-th batch's launch only: a pair costs two ~6 us pipeline bubbles around the launch it times.
  * Host-buffer entry point (davo_forward):
  *   "host_chunk" (default 8): windows per sub-batch; the H2D copy of sub-batch i+1 overlaps the kernels of
  *       sub-batch i when B >= 2*host_chunk.  0 = copy the whole batch, then compute.  Results do not change. */
