@@ -158,6 +158,11 @@ int davo_set_activation_shifts(davo_ctx* ctx, const int* shifts);
  *   "patch_cnv2", "patch_cnv3" (default 1): cnv2 (5x5 stride 2) / cnv3 (3x3 dilation 2) read their taps from an LDS-staged
  *       input patch (csrc/conv_patch_h3.h); 0 = the implicit-GEMM kernel.  The two sum a pixel's taps in different orders:
  *       poses agree to float32 rounding.
+ *   "share_taps" (default 1): cnv3..cnv6 on the 256-row tiles stage ONE pixel patch per filter row for its three kx taps
+ *       (csrc/conv_igemm_h3.h, RATE > 0); 0 = a staged chunk per tap.  Bit-identical results.
+ *   "cu_partition" (default 0; with davo_set_inflight(ctx, n > 1)): slot i's stream is CU-masked to its own 1/n of every
+ *       XCD's compute units (hipExtStreamCreateWithCUMask) and its launches are planned for that many CUs.  Measured
+ *       without gain; kept for experiments.  Results do not change.
  *   "force_tile" (test hook, default -1 = the launch planner decides): tile id of csrc/plan.h (0 128x32, 1 256x64,
  *       2 256x128, 3 128x256, 4 128x128, 5 256x256, 6 208x256); every f16x3 layer the tile fits is issued as one
  *       launch of that shape.  Poses do not depend on it beyond float32 rounding of the fused pose head's sums.
