@@ -198,11 +198,14 @@ def main():
             # every algorithmic FLOP costs three fp16 MFMA FLOPs (hi*hi, hi*lo, lo*hi), so the
             # matrix-pipe roofline of this algorithm is the fp16 dense peak / 3
             peak = PEAK_F16_MFMA_TFLOPS / 3.0
-            tiles = {0: "128x32", 1: "256x64", 2: "256x128", 3: "128x256", 4: "128x128", 5: "256x256", 6: "208x256"}
-            kname = ("davo::conv_igemm_h3<3,1,...,6,true,false,true> (cnv6 main launch: rotation|translation fused, N=256, "
-                     "K=2304, %s tile, LDS-DMA staged, v_mfma_f32_16x16x32_f16)" % tiles.get(plan[0][1], "?"))
+            tiles = {0: "128x32", 1: "256x64", 2: "256x128", 3: "128x256", 4: "128x128", 5: "256x256", 6: "208x256",
+                     7: "256x256 + 128x128 remainder tiles in one grid"}
+            merged = plan[0][1] == 7
+            kname = ("davo::%s (cnv6 %s: rotation|translation fused, N=256, K=2304, %s tile, LDS-DMA staged, "
+                     "v_mfma_f32_16x16x32_f16)" % ("conv_igemm_h3_mainrem<6,2>" if merged else "conv_igemm_h3<3,1,...,6,true,false,true>",
+                                                   "whole layer, one launch" if merged else "main launch", tiles.get(plan[0][1], "?")))
             peak_note = "fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP; frac = matrix-pipe utilisation"
-            key = "conv_igemm_h3<3, 1, "
+            key = "conv_igemm_h3_mainrem<6" if merged else "conv_igemm_h3<3, 1, "
         # HBM traffic of the dominant kernel: from the most recent committed PMC pass (profiles/), not live —
         # rocprofv3 counter collection cannot run inside the timed process
         traffic, traffic_src = None, None
@@ -212,7 +215,7 @@ def main():
                 tj = json.load(open(f))
                 if tj.get("batch", 32) != B or (H, W) != (128, 416):
                     continue
-                hit = [v for k, v in tj["kernels"].items() if key in k and (precision == "f32" or ", 6, true, false" in k)]
+                hit = [v for k, v in tj["kernels"].items() if key in k and (precision == "f32" or "mainrem" in key or ", 6, true, false" in k)]
                 if hit:
                     hit.sort(key=lambda v: -(v["read_bytes"] + v["write_bytes"]))
                     traffic = hit[0]["read_bytes"] + hit[0]["write_bytes"]

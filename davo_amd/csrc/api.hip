@@ -443,6 +443,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     if (k == "fuse_pose") c->opt_fuse_pose = value != 0;
     else if (k == "fuse_pack") c->opt_fuse_pack = value != 0;
     else if (k == "share_taps") c->opt_share_taps = value != 0;
+    else if (k == "merge_rem") c->opt_merge_rem = value != 0;
     else if (k == "patch_cnv2") c->opt_patch_cnv2 = value != 0;
     else if (k == "patch_cnv3") c->opt_patch_cnv3 = value != 0;
     else if (k == "force_tile") {

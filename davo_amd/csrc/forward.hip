@@ -187,6 +187,24 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         if (pose_ntn) *pose_ntn = ntn;
     }
     c->last_plan[li][0] = c->last_plan[li][1] = 0;
+    if (c->opt_merge_rem && !fuse_pose && plan.size() == 2 && plan[0].tile == TILE_256x256 && plan[1].tile == TILE_128x128 &&
+        L.groups == 1 && L.npad_h == 256 && c->ncu == 256 && !tuning_env("DAVO_NO_MERGE")) {
+        // main + remainder as one grid (conv_igemm_h3_mainrem): same tiles, same arithmetic, de-phased store bursts
+        ConvParamsH pm = p, pr = p;
+        pm.ntiles_n = 1; pm.mtile0 = 0; pm.M = plan[0].rows;
+        pr.ntiles_n = 2; pr.mtile0 = plan[1].row0 / 128; pr.M = plan[1].row0 + plan[1].rows;
+        const int n_main = plan[0].rows / 256, n_rem = ((plan[1].rows + 127) / 128) * 2;
+        hipError_t e;
+        {
+            ProfScope ps(c, L.label);
+            e = launch_layer_h3_mainrem(li, pm, n_main, pr, n_rem, c->stream);
+        }
+        if (e == hipSuccess) {
+            c->last_plan[li][0] = ((plan[0].rows + plan[1].rows + 127) / 128) * 1000 + 7;     // 7: 256x256 + 128x128 in one grid
+            return DAVO_OK;
+        }
+        if (e != hipErrorNotSupported) HIP_TRY(c, e);
+    }
     for (size_t i = 0; i < plan.size() && i < 2; ++i) {
         const TileShape ts = tile_shape(plan[i].tile);
         p.ntiles_n = L.npad_h / ts.bn;

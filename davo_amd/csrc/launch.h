@@ -22,6 +22,9 @@ hipError_t launch_layer(int layer, int BN, const ConvParams& p, dim3 grid, hipSt
 
 // ---- launch_h3.hip: conv_igemm_h3 (f16x3) -----------------------------------------------------------
 hipError_t launch_layer_h3(int layer, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s);
+// main launch (256x256 tiles, shared-tap staging) + remainder launch (128x128 tiles) of cnv5 / cnv6 (layer 4 / 5) as one grid
+// (conv_igemm_h3_mainrem); hipErrorNotSupported when the two launches do not have that shape: the caller issues them separately
+hipError_t launch_layer_h3_mainrem(int layer, const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, hipStream_t s);
 // launch_h3s.hip: conv_igemm_h3s (TILE_208x256) for layer 4..6 = cnv5, cnv6, cnv7
 hipError_t launch_layer_h3s(int layer, const ConvParamsH& p, dim3 grid, hipStream_t s);
 hipError_t launch_h3_generic(int KS, int stride, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s);

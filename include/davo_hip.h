@@ -158,6 +158,10 @@ int davo_set_activation_shifts(davo_ctx* ctx, const int* shifts);
  *   "patch_cnv2", "patch_cnv3" (default 1): cnv2 (5x5 stride 2) / cnv3 (3x3 dilation 2) read their taps from an LDS-staged
  *       input patch (csrc/conv_patch_h3.h); 0 = the implicit-GEMM kernel.  The two sum a pixel's taps in different orders:
  *       poses agree to float32 rounding.
+ *   "merge_rem" (default 1): where cnv5 / cnv6 are planned as a main launch of 256x256 tiles plus a remainder launch of
+ *       128x128 tiles (B = 32), both run as ONE grid in which half of the CUs take their remainder tile first and the other
+ *       half last (csrc/conv_igemm_h3.h, conv_igemm_h3_mainrem): the halves' store bursts no longer coincide.  0 = two
+ *       launches.  Same tiles, same kernels' arithmetic: bit-identical results.
  *   "share_taps" (default 1): cnv3..cnv6 on the 256-row tiles stage ONE pixel patch per filter row for its three kx taps
  *       (csrc/conv_igemm_h3.h, RATE > 0); 0 = a staged chunk per tap.  Bit-identical results.
  *   "cu_partition" (default 0; with davo_set_inflight(ctx, n > 1)): slot i's stream is CU-masked to its own 1/n of every

@@ -758,6 +758,35 @@ def test_tile_208x256_forced(c_oracle, B, H, W):
     e.close()
 
 
+# ---- main + remainder launch of cnv5 / cnv6 as one grid (conv_igemm_h3_mainrem) ----------------------------
+@pytest.mark.gpu
+def test_merged_main_and_remainder_launch_is_bit_identical(c_oracle):
+    """At B=32 cnv5 and cnv6 are 3.25 rounds of 256x256 tiles: a main launch of 3 whole rounds plus a remainder launch of
+    128x128 tiles.  `merge_rem` (default) runs both tile shapes in ONE grid, half of the CUs taking their remainder tile
+    first and the other half last, so that the halves' store bursts do not coincide.  Same tiles, same arithmetic: every
+    activation and pose is bit-identical to the two-launch plan; the plan reports tile id 7 for the merged layers."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B, H, W = 32, 128, 416
+    img, flow, seg = synth.make_inputs(B, H, W, first_window=5)
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, H, W, B, weights, "f16x3")
+    e.set_option("host_chunk", 0)                            # the whole batch as one step (the host entry's default chunks of 8 plan otherwise)
+    e.set_option("fuse_pose", 0)
+    e.set_option("merge_rem", 0)
+    base = e.forward(img, flow, seg).copy()
+    assert [t for _, t in e.last_plan(4)] == [5, 4] and [t for _, t in e.last_plan(5)] == [5, 4]
+    a5 = e.debug_read("cnv5", (2 * B, 32, 104, 256)).copy()
+    a6 = e.debug_read("cnv6", (2 * B, 32, 104, 256)).copy()
+    e.set_option("merge_rem", 1)
+    got = e.forward(img, flow, seg)
+    assert [t for _, t in e.last_plan(4)] == [7] and [t for _, t in e.last_plan(5)] == [7]
+    assert np.array_equal(e.debug_read("cnv5", (2 * B, 32, 104, 256)), a5)
+    assert np.array_equal(e.debug_read("cnv6", (2 * B, 32, 104, 256)), a6)
+    assert np.array_equal(got, base)
+    assert_pose_close(got[:4], c_oracle.forward(cfg, img[:4], flow[:4], seg[:4], weights), "merged launch")
+    e.close()
+
+
 # ---- repeatability under load: the hand-counted waits of the f16x3 kernels ---------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W", [(32, 128, 416), (16, 128, 416), (7, 52, 172)])
