@@ -9,7 +9,12 @@ same per-GPU batch on its own windows (weak scaling, no data-path collective: wi
 independent, test_kitti_pose.py:134-145); after the timed region the ranks' poses meet once in an
 RCCL all-gather (davo_amd/comm.py), reported separately and not part of `value`.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--height H --width W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--settle S] [--batch B] [--height H --width W] [--force-comm]
+
+Untimed before the timed region: W warm-up steps, then S settle steps (default: whatever brings W + S to 100) — the
+chip's clock needs ~25 steps (30 ms) of this load to settle after idle; `settle_steps` is disclosed in the JSON and the
+timed region is exactly K full forwards either way.  `timing` in the JSON shows the ramp that is left: per-step periods
+and the dominant launch's durations at the start and at the end of the timed region.
 
 `--gpus N` with N > 1 starts the N ranks itself (davo_amd/launch.py: a parent that touches no GPU and
 returns non-zero if any rank does); started under `python -m torch.distributed.run --nproc-per-node N`
@@ -67,6 +72,20 @@ def cpu_model():
     return "unknown"
 
 
+def workload_name(B, H, W, world):
+    """the BASELINE.json configuration the arguments select (or none of them)"""
+    net = "dilatedPoseNN-cnv6_128 + se_flow + fc_tanh (segmask_all + abs_flow)"
+    shape = "batch=%d/GPU synthetic %dx%d RGB+flow+seg triplets, %s" % (B, H, W, net)
+    if (B, H, W) == (32, 128, 416):
+        return "BASELINE.json configs[1]: single MI355X, batch=32 synthetic 128x416 triplets" + (
+            "" if world == 1 else " (x%d window-sharded replicas)" % world) + ", " + net
+    if (B, H, W) == (128, 128, 416):
+        return "BASELINE.json configs[2]: single MI355X, batch=128, same net" + ("" if world == 1 else " (x%d replicas)" % world)
+    if (B, H, W) == (64, 256, 832):
+        return "BASELINE.json configs[4] per-GPU shape: 256x832, batch=64/GPU, segmask_all + abs_flow (%d GPU%s)" % (world, "" if world == 1 else "s")
+    return "none of BASELINE.json's configs: " + shape
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +94,12 @@ def parse_args():
     # DESIGN.md section 6a); 5 warm-up steps time the ramp, not the path.
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--settle", type=int, default=-1,
+                    help="untimed steps after the warm-up, before the timed region (clock settle; disclosed as settle_steps). "
+                         "Default -1: max(0, 100 - warmup)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="build the RCCL communicator at world size 1 too, so the barrier / max all-reduce / gather code of the "
+                         "multi-GPU run executes on one GPU")
     ap.add_argument("--batch", type=int, default=32, help="triplets per GPU per step")
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=416)
@@ -89,7 +114,7 @@ def parse_args():
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra 2-in-flight throughput measurement (used for the rocprofv3 passes, so that "
                          "per-kernel statistics are not mixed with overlapped launches)")
-    ap.add_argument("--no-f32", action="store_true", help="skip the strict-float32 leg (roofline_f32)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the strict-float32 leg (roofline.reference_arithmetic)")
     ap.add_argument("--profile-stride", type=int, default=0,
                     help="HIP events around the dominant kernel of every n-th timed step (default: 4 when steps >= 40, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,7 +145,8 @@ def main():
     eng = Engine(cfg, H, W, B, device=device_index)  # raises without a GPU: the HIP path has no CPU fallback
     eng.load_weights(weights)
     eng.set_precision(args.precision)
-    comm = RcclComm(eng, rank, world) if world > 1 else None     # raises on any RCCL failure: no gloo, no TCP stand-in
+    # raises on any RCCL failure: no gloo, no TCP stand-in
+    comm = RcclComm(eng, rank, world) if (world > 1 or args.force_comm) else None
 
     # synthetic windows of this rank's shard, resident in HBM before the timed region; one buffer set per
     # in-flight slot (consecutive steps work on different batches of the shard)
@@ -159,18 +185,34 @@ def main():
         sync_all()
         return max_over_ranks(time.perf_counter() - t0)
 
-    for i in range(args.warmup):
+    settle = args.settle if args.settle >= 0 else max(0, 100 - args.warmup)
+    for i in range(args.warmup + settle):
         eng.forward_device(B, *sets[i % nset])
     eng.synchronize()
 
     # timed region: K steps; only the dominant kernel (main cnv6 launch) is bracketed by HIP events
     # on the launch stream, so the event records do not perturb the other launches
     # (every 4th step: an event pair puts two ~6 us bubbles around the launch it brackets - 1 % of the step if every launch is timed)
+    stride = args.profile_stride or (4 if args.steps >= 40 else 1)
     eng.profile(2)
-    eng.set_option("profile_stride", args.profile_stride or (4 if args.steps >= 40 else 1))
+    eng.set_option("profile_stride", stride)
     eng.profile_reset()
     elapsed_max = timed(lambda k: [eng.forward_device(B, *sets[i % nset]) for i in range(k)], args.steps)
     dominant = eng.profile_entries()
+    dom_dur, dom_period = eng.profile_samples("cnv6")
+
+    def head_tail(x):
+        x = [float(v) for v in x]
+        k = max(1, min(5, len(x) // 2))
+        return {"n": len(x), "first%d_mean" % k: round(sum(x[:k]) / k, 4), "last%d_mean" % k: round(sum(x[-k:]) / k, 4),
+                "min": round(min(x), 4), "max": round(max(x), 4)} if x else None
+    # the ramp that is left inside the timed region, from the events that bracket the dominant launch anyway: a bracketed
+    # launch's own duration, and the stream time between the starts of consecutive bracketed launches (= stride steps)
+    timing = {"warmup_steps": args.warmup, "settle_steps": settle, "timed_steps": args.steps, "bracketed_every": stride,
+              "dominant_launch_ms": head_tail(dom_dur),
+              "step_ms_on_stream": head_tail([p / stride for p in dom_period if p >= 0]),
+              "note": "untimed = warmup + settle (clock ramp after idle, DESIGN.md 6a); the timed region is exactly `steps` full "
+                      "forwards; step_ms_on_stream = time between the starts of consecutive bracketed cnv6 launches / stride"}
     plan6 = eng.last_plan(5)                          # [(128-row M tiles, N tile | f16x3 tile id), ...]
     # untimed extra pass, one batch in flight: per-kernel breakdown (every launch bracketed)
     eng.set_inflight(1)
@@ -286,16 +328,24 @@ def main():
         g0 = time.perf_counter()
         allp, coll_ms = comm.allgather(poses)
         wall_ms = (time.perf_counter() - g0) * 1e3
-        if not np.array_equal(allp[rank * B:(rank + 1) * B], poses):
+        if allp.shape != (world * B, 2, 6) or not np.array_equal(allp[rank * B:(rank + 1) * B], poses):
             raise SystemExit("rank %d: the RCCL all-gather did not return this rank's own poses" % rank)
-        gather = {"backend": "rccl (librccl via davo_allgather_poses)", "bytes_per_rank": int(poses.nbytes),
-                  "collective_ms": round(coll_ms, 4), "wall_ms_incl_staging": round(wall_ms, 3)}
+        # every rank ran the same weights on its own windows: the shards must all be finite and (world > 1) differ
+        n_distinct = len({allp[r * B:(r + 1) * B].tobytes() for r in range(world)})
+        if not np.isfinite(allp).all() or n_distinct != world:
+            raise SystemExit("rank %d: gathered shards are not %d distinct finite pose blocks" % (rank, world))
+        gather = {"backend": "rccl (librccl via davo_allgather_poses)", "ranks": world, "bytes_per_rank": int(poses.nbytes),
+                  "collective_ms": round(coll_ms, 4), "wall_ms_incl_staging": round(wall_ms, 3),
+                  "distinct_shards": n_distinct, "forced_at_world_1": bool(args.force_comm and world == 1)}
 
     if rank == 0:
         value = world * B * args.steps / elapsed_max
         kern_ms = {k: round(v[1] / max(v[0], 1), 4) for k, v in kernels.items()}
         whole = flops_per_triplet * B * args.steps / elapsed_max / 1e12
         roof = roofline_block(args.precision, dominant, plan6)
+        # the like-for-like leg (the reference computes in float32, nets/posenn.py:205-215) rides inside `roofline`
+        roof["reference_arithmetic"] = f32_block
+        roof["whole_path_frac_of_mfma_peak"] = round(whole / roof["peak"], 4)
         dtype = "f32" if args.precision == "f32" else "f16x3 (fp16 hi/lo split operands, 3 MFMA products, f32 accumulate)"
         # the HBM-bound front of the path: algorithmic bytes / kernel time from the per-kernel breakdown pass
         sq_ms, mp_ms = kern_ms.get("se_squeeze_partial", 0.0), kern_ms.get("mask_pack", 0.0)
@@ -319,16 +369,16 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic (splitmix64 seed 8964; random-init He-uniform weights; no KITTI/ckpt offline)",
-            "config": {"workload": "BASELINE.json configs[1]: single MI355X, batch=%d synthetic %dx%d RGB+flow+seg "
-                                   "triplets, dilatedPoseNN-cnv6_128 + se_flow + fc_tanh" % (B, H, W),
+            "config": {"workload": workload_name(B, H, W, world),
                        "version": FLAGSHIP_VERSION, "batch_per_gpu": B, "height": H, "width": W,
                        "parallelism": "window-sharded replicas x%d" % world, "batches_in_flight": nset},
             "roofline": roof,
+            "timing": timing,
             "whole_path_tflops_per_gpu": round(whole, 2),
             "whole_path_frac_of_mfma_peak": round(whole / roof["peak"], 4),
             "roofline_prologue": pro,
             "kernel_avg_ms": kern_ms,
-            "roofline_f32": f32_block,
+            "range_recovery": eng.range_stats(),
             "pipelined": pipelined,
             "gather": gather,
         }

@@ -27,8 +27,8 @@ EXPORTS = (
     "davo_create", "davo_load_weight", "davo_weights_missing", "davo_forward", "davo_forward_device",
     "davo_last_error", "davo_destroy", "davo_device_malloc", "davo_device_free", "davo_memcpy_h2d",
     "davo_memcpy_d2h", "davo_synchronize", "davo_set_stream", "davo_set_inflight", "davo_profile_enable",
-    "davo_profile_reset", "davo_profile_entry", "davo_last_plan", "davo_set_option", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
-    "davo_host_alloc", "davo_host_free", "davo_calibrate", "davo_activation_range", "davo_set_activation_shifts",
+    "davo_profile_reset", "davo_profile_entry", "davo_profile_samples", "davo_last_plan", "davo_set_option", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
+    "davo_host_alloc", "davo_host_free", "davo_calibrate", "davo_activation_range", "davo_set_activation_shifts", "davo_range_stats",
     "davo_comm_unique_id", "davo_comm_init", "davo_comm_size", "davo_allgather_poses", "davo_allgather_poses_device",
     "davo_comm_allreduce", "davo_comm_barrier", "davo_comm_destroy", "davo_plan_layer",
 )
@@ -107,6 +107,8 @@ def lib():
     L.davo_calibrate.argtypes = [vp, i, vp, vp, vp, ctypes.POINTER(i)]
     L.davo_activation_range.argtypes = [vp, f32p, ctypes.POINTER(i), i]
     L.davo_set_activation_shifts.argtypes = [vp, ctypes.POINTER(i)]
+    llp = ctypes.POINTER(ctypes.c_longlong)
+    L.davo_range_stats.argtypes = [vp, llp, llp, llp]
     L.davo_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_size_t]
     L.davo_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_size_t]
     L.davo_synchronize.argtypes = [vp]
@@ -115,6 +117,7 @@ def lib():
     L.davo_profile_enable.argtypes = [vp, i]
     L.davo_profile_reset.argtypes = [vp]
     L.davo_profile_entry.argtypes = [vp, i, ctypes.c_char_p, i, ctypes.POINTER(i), ctypes.POINTER(ctypes.c_double)]
+    L.davo_profile_samples.argtypes = [vp, ctypes.c_char_p, i, f32p, i]
     L.davo_last_plan.argtypes = [vp, i, i, ctypes.POINTER(i), ctypes.POINTER(i)]
     L.davo_set_option.argtypes = [vp, ctypes.c_char_p, i]
     L.davo_set_precision.argtypes = [vp, i]

@@ -7,12 +7,16 @@ is created on librccl itself — no ``torch.distributed``, no fallback transport
 loaded or initialised the run fails.
 
 The 128-byte ``ncclUniqueId`` travels from rank 0 to the other ranks through a small file:
-``$DAVO_COMM_FILE``, or ``$DAVO_COMM_DIR/rccl_id`` (``davo_amd.launch.spawn_ranks`` creates a fresh
-directory per run), or — under ``python -m torch.distributed.run``, which sets neither — a name built
-from the launcher's PID and ``MASTER_PORT`` in the temp directory.
+``$DAVO_COMM_FILE``, or ``$DAVO_COMM_DIR/rccl_id[.$DAVO_COMM_NONCE]`` (``davo_amd.launch.spawn_ranks`` creates a fresh
+private directory and a random nonce per run), or — under ``python -m torch.distributed.run``, which sets neither — a
+file in a private per-user directory whose name carries the launcher's PID, ``MASTER_PORT`` and the elastic agent's
+run id and restart count, so a restarted worker group never reads the id of the group before it.  Rank 0 creates the
+file exclusively (``O_EXCL``, mode 0600); a reader accepts it only if it is the reader's own (same uid) and not older
+than the launcher process itself.
 """
 import ctypes
 import os
+import stat
 import tempfile
 import time
 
@@ -20,7 +24,22 @@ import numpy as np
 
 from . import _lib
 
-_START = time.time()
+
+class CommError(RuntimeError):
+    pass
+
+
+def _private_dir():
+    """per-user 0700 directory under the temp dir (another local user can neither read nor pre-plant an id file)"""
+    d = os.path.join(tempfile.gettempdir(), "davo_comm_uid%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise CommError("%s is not a private directory of uid %d" % (d, os.getuid()))
+    return d
 
 
 def rendezvous_path():
@@ -29,17 +48,29 @@ def rendezvous_path():
         return f
     d = os.environ.get("DAVO_COMM_DIR")
     if d:
-        return os.path.join(d, "rccl_id")
-    return os.path.join(tempfile.gettempdir(), "davo_comm_%d_%d_%s.id" % (os.getuid(), os.getppid(), os.environ.get("MASTER_PORT", "0")))
+        nonce = os.environ.get("DAVO_COMM_NONCE")
+        return os.path.join(d, "rccl_id" + ("." + nonce if nonce else ""))
+    tag = "_".join(str(os.environ.get(k, "0")) for k in ("MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"))
+    tag = "".join(ch if ch.isalnum() or ch in "_-" else "-" for ch in tag)
+    return os.path.join(_private_dir(), "rccl_%d_%s.id" % (os.getppid(), tag))
+
+
+def _launcher_start_time():
+    """wall-clock start of the parent process (the launcher every rank shares): an id file older than it belongs to an
+    earlier run.  Falls back to 0 (no age test) where /proc is not readable."""
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])          # field 22: starttime in clock ticks since boot
+        with open("/proc/stat") as f:
+            btime = next(int(l.split()[1]) for l in f if l.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK") - 1.0             # btime is whole seconds
+    except (OSError, ValueError, StopIteration, IndexError):
+        return 0.0
 
 
 def world_from_env():
     """(rank, local_rank, world) as the launch contract sets them (RANK / LOCAL_RANK / WORLD_SIZE)."""
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-
-
-class CommError(RuntimeError):
-    pass
 
 
 class RcclComm:
@@ -58,15 +89,23 @@ class RcclComm:
             if rc != 0:
                 raise CommError("davo_comm_unique_id: %s" % err.value.decode())
             tmp = "%s.%d.tmp" % (path, os.getpid())
-            with open(tmp, "wb") as f:
+            for stale in (tmp, path):                   # a file of this very name can only be a leftover of this launcher's
+                try:
+                    os.remove(stale)
+                except OSError:
+                    pass
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            with os.fdopen(fd, "wb") as f:
                 f.write(bytes(ident))
             os.replace(tmp, path)                       # readers see all 128 bytes or no file
         else:
             t0 = time.time()
+            not_before = _launcher_start_time()
             while True:
                 try:
-                    # a file left behind by an earlier, crashed run under the same name is older than this process
-                    if os.path.getsize(path) == _lib.COMM_ID_BYTES and os.path.getmtime(path) >= _START - 60.0:
+                    st = os.stat(path)
+                    # the reader's own file (uid), complete, and written under THIS launcher
+                    if st.st_size == _lib.COMM_ID_BYTES and st.st_uid == os.getuid() and st.st_mtime >= not_before:
                         with open(path, "rb") as f:
                             raw = f.read()
                         if len(raw) == _lib.COMM_ID_BYTES:

@@ -60,6 +60,12 @@ int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const d
     HIP_TRY(c, hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(c, DAVO_ERR_INVALID, "device %d not present (%d visible)", device, ndev);
     HIP_TRY(c, hipSetDevice(device));
+    {   // the launch planner sizes whole rounds for the CUs this device really has (a partitioned MI355X exposes fewer than 256)
+        hipDeviceProp_t prop;
+        HIP_TRY(c, hipGetDeviceProperties(&prop, device));
+        c->dev_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        c->ncu = c->dev_cus;
+    }
     c->needed = needed_names(c->v);
 
     c->H1 = (H + 1) / 2; c->W1 = (W + 1) / 2;
@@ -127,27 +133,133 @@ int davo_weights_missing(davo_ctx* c) {
     return n;
 }
 
-// read the range record of the f16x3 forwards issued since the last check and judge it (forward.hip:
-// check_range).  Called with every stream of the context idle.  The first batch issued afterwards starts a
-// fresh record (davo_forward_device / davo_forward).
-static int consume_range_record(davo_ctx* c) {
-    if (!c->range_dirty || !c->d_range) return DAVO_OK;
+// ---- f16x3 range verdicts and recovery -----------------------------------------------------------------
+// The reference's float32 graph (nets/posenn.py:205-215, davo.py:1553-1569) never fails on a finite network, so the
+// default f16x3 arithmetic must not either: a batch whose range record fails the verdict is re-issued here - first
+// with the storage scales re-calibrated on that very batch, and if it still leaves the fp16-pair range, on the
+// library's own float32 kernels (davo_set_precision(ctx, 0) for that batch only).  "auto_range" 0 restores the plain
+// DAVO_ERR_RANGE verdict.
+namespace {
+
+constexpr size_t PENDING_CAP = 4096;             // device-path batches remembered between verdicts
+
+int read_range_record(davo_ctx* c, unsigned raw[6]) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(raw, c->d_range, 6 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return DAVO_OK;
+}
+
+// power-of-two storage scales from a sample batch: each pass runs the path and moves every layer's largest stored
+// value into [512, 1024).  A layer computed from badly ranged inputs still has about the right magnitude, so each
+// pass fixes at least the first badly ranged layer exactly and the later ones to within a few powers of two.
+int calibrate_on(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, void* d_pose) {
+    int rc = DAVO_OK;
+    const int save_precision = c->precision, save_impl = c->impl;
+    c->precision = 1; c->impl = 0;
+    for (int pass = 0; pass < 8 && rc == DAVO_OK; ++pass) {
+        if (hipMemset(c->d_range, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = fail(c, DAVO_ERR_HIP, "hipMemset failed"); break; }
+        rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
+        if (rc) break;
+        unsigned raw[6];
+        if ((rc = read_range_record(c, raw))) break;
+        bool changed = false;
+        for (int i = 0; i < 6; ++i) {
+            float v;
+            memcpy(&v, &raw[i], sizeof v);
+            int delta = 0;
+            if (!std::isfinite(v)) delta = -32;
+            else if (v > 0.f) { int e; (void)frexpf(v, &e); delta = 10 - e; }        // stored max -> [2^9, 2^10): 64x headroom
+            int ns = c->act_shift[i] + delta;
+            ns = ns < -60 ? -60 : (ns > 60 ? 60 : ns);
+            if (ns != c->act_shift[i]) { c->act_shift[i] = ns; changed = true; }
+        }
+        if (!changed) break;
+    }
+    c->precision = save_precision; c->impl = save_impl;
+    (void)hipMemset(c->d_range, 0, 8 * sizeof(unsigned));
+    c->range_dirty = false;
+    return rc;
+}
+
+// one batch, synchronously, with a record of its own; -> DAVO_OK, DAVO_ERR_RANGE (the verdict) or a hard error
+int run_judged(davo_ctx* c, const PendingBatch& b) {
+    HIP_TRY(c, hipMemsetAsync(c->d_range, 0, 8 * sizeof(unsigned), c->stream));
+    int rc = forward_device(c, b.B, b.img, b.flow, b.seg, b.pose);
+    if (rc) return rc;
+    unsigned raw[6];
+    if ((rc = read_range_record(c, raw))) return rc;
+    c->range_dirty = false;
+    return c->last_precision == 1 ? check_range(c, raw) : DAVO_OK;
+}
+
+// Every stream idle.  Re-issue the batches a failed verdict covered (one record serves all batches between two
+// verdicts, so all of them): as issued if the batch is inside the range after all, re-calibrated on itself if not,
+// on the float32 kernels if even that leaves the range (per-layer scales cannot cover e.g. an inf / NaN producing net).
+int recover_batches(davo_ctx* c, const std::vector<PendingBatch>& list) {
+    std::vector<PendingBatch> todo;              // each distinct batch once, in the order of its LAST issue
+    for (size_t i = 0; i < list.size(); ++i) {
+        bool later = false;
+        for (size_t j = i + 1; j < list.size() && !later; ++j) later = list[j] == list[i];
+        if (!later) todo.push_back(list[i]);
+    }
+    activate_slot(c, 0);
+    for (const PendingBatch& b : todo) {
+        int rc = run_judged(c, b);
+        if (rc == DAVO_ERR_RANGE) {
+            if ((rc = calibrate_on(c, b.B, b.img, b.flow, b.seg, b.pose))) return rc;
+            ++c->n_recalibrations;
+            rc = run_judged(c, b);
+        }
+        if (rc == DAVO_ERR_RANGE) {
+            const int save = c->precision;
+            c->precision = 0;
+            rc = forward_device(c, b.B, b.img, b.flow, b.seg, b.pose);
+            c->precision = save;
+            if (rc == DAVO_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, DAVO_ERR_HIP, "hipStreamSynchronize failed");
+            ++c->n_f32_batches;
+        }
+        if (rc) return rc;
+        ++c->n_reissued;
+    }
+    HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned)));
+    c->range_dirty = false;
+    c->err.clear();
+    return DAVO_OK;
+}
+
+// Verdict on the f16x3 batches davo_forward_device issued since the last one.  Waits for every stream of the context.
+int judge_pending(davo_ctx* c) {
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    if (!c->range_dirty || !c->d_range) { c->pending.clear(); return DAVO_OK; }
     unsigned raw[6];
     HIP_TRY(c, hipMemcpy(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost));
     c->range_dirty = false;            // judged; the record itself stays readable (davo_activation_range) until the next batch
-    return check_range(c, raw);
+    std::vector<PendingBatch> list;
+    list.swap(c->pending);
+    const int rc = check_range(c, raw);
+    if (rc != DAVO_ERR_RANGE || !c->opt_auto_range || list.empty()) return rc;
+    return recover_batches(c, list);
 }
+
+}  // namespace
 
 int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg,
                         void* d_pose, float* elapsed_ms) {
     if (!c) return DAVO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the list of unjudged batches is bounded: a caller that never synchronises gets a verdict every PENDING_CAP batches
+    if (c->pending.size() >= PENDING_CAP) { int rc = judge_pending(c); if (rc) return rc; }
     // rotate through the in-flight slots: this batch runs on its own stream and workspace
     activate_slot(c, c->next_slot);
     c->next_slot = (c->next_slot + 1) % c->inflight;
-    HIP_TRY(c, hipSetDevice(c->device));
     // first batch since the last verdict: no unjudged batch is in flight, so the record can start afresh
     if (!c->range_dirty && c->d_range) HIP_TRY(c, hipMemsetAsync(c->d_range, 0, 8 * sizeof(unsigned), c->stream));
-    if (!elapsed_ms) return forward_device(c, B, d_img, d_flow, d_seg, d_pose);
+    const PendingBatch me{B, d_img, d_flow, d_seg, d_pose};
+    if (!elapsed_ms) {
+        const int rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
+        if (rc == DAVO_OK && c->last_precision == 1 && c->opt_auto_range) c->pending.push_back(me);
+        return rc;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = DAVO_OK;
     auto hip_ok = [&](hipError_t e, const char* what) {
@@ -163,8 +275,9 @@ int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flo
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    // the timed form is synchronous, so it can judge the range record of its own batch
-    if (rc == DAVO_OK && c->inflight == 1) rc = consume_range_record(c);
+    if (rc == DAVO_OK && c->last_precision == 1 && c->opt_auto_range) c->pending.push_back(me);
+    // the timed form is synchronous, so it can judge (and, if need be, re-issue) its own batch; elapsed_ms is the first issue's
+    if (rc == DAVO_OK && c->inflight == 1) rc = judge_pending(c);
     return rc;
 }
 
@@ -184,7 +297,8 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
         HIP_TRY(c, hipMalloc(&c->s_pose, (size_t)c->max_batch * 12 * sizeof(float)));
     }
     if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    { int rc = consume_range_record(c); if (rc) return rc; }    // device-path batches issued before this call
+    { int rc = judge_pending(c); if (rc) return rc; }           // device-path batches issued before this call
+    activate_slot(c, 0);
     HIP_TRY(c, hipMemsetAsync(c->d_range, 0, 8 * sizeof(unsigned), c->stream));      // the monitor covers this call
     // Sub-batches: the copy of chunk i+1 (copy_stream) overlaps the kernels of chunk i (compute stream).
     // Results do not depend on the split (windows are independent; tests/test_hip_parity.py batch invariance).
@@ -215,7 +329,22 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
     HIP_TRY(c, hipMemcpyAsync(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->range_dirty = false;                                   // judged here
-    return c->last_precision == 1 ? check_range(c, raw) : DAVO_OK;
+    if (c->last_precision != 1) return DAVO_OK;
+    int rc = check_range(c, raw);
+    if (rc == DAVO_ERR_RANGE && c->opt_auto_range) {
+        // the staged copy of the batch is still in HBM: re-issue it whole (recalibrated, or on the float32 kernels)
+        rc = recover_batches(c, {PendingBatch{B, c->s_img, c->s_flow, c->s_seg, c->s_pose}});
+        if (rc == DAVO_OK) HIP_TRY(c, hipMemcpy(pose_out, c->s_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return rc;
+}
+
+int davo_range_stats(davo_ctx* c, long long* recalibrations, long long* f32_batches, long long* reissued) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (recalibrations) *recalibrations = c->n_recalibrations;
+    if (f32_batches) *f32_batches = c->n_f32_batches;
+    if (reissued) *reissued = c->n_reissued;
+    return DAVO_OK;
 }
 
 int davo_activation_range(davo_ctx* c, float* max_abs, int* shifts, int reset) {
@@ -250,40 +379,11 @@ int davo_calibrate(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
     if (!d_img || !d_flow || !d_seg) return fail(c, DAVO_ERR_INVALID, "null device pointer");
     HIP_TRY(c, hipSetDevice(c->device));
-    { int rc = sync_all_slots(c); if (rc) return rc; }
+    { int rc = judge_pending(c); if (rc) return rc; }         // batches issued under the old scales get their verdict first
     activate_slot(c, 0);
     float* d_pose = nullptr;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_pose), (size_t)B * 12 * sizeof(float)));
-    int rc = DAVO_OK;
-    const int save_precision = c->precision, save_impl = c->impl;
-    c->precision = 1; c->impl = 0;
-    // A layer computed from badly ranged inputs still has about the right magnitude, so each pass fixes at
-    // least the first badly ranged layer exactly and the later ones to within a few powers of two.
-    for (int pass = 0; pass < 8 && rc == DAVO_OK; ++pass) {
-        if (hipMemset(c->d_range, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = fail(c, DAVO_ERR_HIP, "hipMemset failed"); break; }
-        rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
-        if (rc) break;
-        unsigned raw[6];
-        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost) != hipSuccess) {
-            rc = fail(c, DAVO_ERR_HIP, "reading the activation ranges failed");
-            break;
-        }
-        bool changed = false;
-        for (int i = 0; i < 6; ++i) {
-            float v;
-            memcpy(&v, &raw[i], sizeof v);
-            int delta = 0;
-            if (!std::isfinite(v)) delta = -32;
-            else if (v > 0.f) { int e; (void)frexpf(v, &e); delta = 10 - e; }        // stored max -> [2^9, 2^10): 64x headroom
-            int ns = c->act_shift[i] + delta;
-            ns = ns < -60 ? -60 : (ns > 60 ? 60 : ns);
-            if (ns != c->act_shift[i]) { c->act_shift[i] = ns; changed = true; }
-        }
-        if (!changed) break;
-    }
-    c->precision = save_precision; c->impl = save_impl;
-    (void)hipMemset(c->d_range, 0, 8 * sizeof(unsigned));
-    c->range_dirty = false;
+    const int rc = calibrate_on(c, B, d_img, d_flow, d_seg, d_pose);
     (void)hipFree(d_pose);
     if (rc == DAVO_OK && shifts_out) for (int i = 0; i < 6; ++i) shifts_out[i] = c->act_shift[i];
     return rc;
@@ -350,10 +450,10 @@ int davo_memcpy_d2h(davo_ctx* c, void* dst, const void* src, size_t bytes) {
 int davo_synchronize(davo_ctx* c) {
     if (!c) return DAVO_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    { int rc = sync_all_slots(c); if (rc) return rc; }
     // f16x3: the batches davo_forward_device issued since the last synchronize are judged here (the asynchronous
-    // entry point cannot know its own result): DAVO_ERR_RANGE = some layer left the fp16-pair storage range
-    return consume_range_record(c);
+    // entry point cannot know its own result).  A failed verdict re-issues them (recover_batches); with "auto_range" 0
+    // it is returned as DAVO_ERR_RANGE = some layer left the fp16-pair storage range
+    return judge_pending(c);
 }
 int davo_set_stream(davo_ctx* c, void* hip_stream) {
     if (!c) return DAVO_ERR_INVALID;
@@ -374,8 +474,21 @@ int davo_profile_reset(davo_ctx* c) {
     if (!c) return DAVO_ERR_INVALID;
     int rc = prof_collect(c);
     if (rc) return rc;
-    for (auto& pe : c->prof_entries) { pe.launches = 0; pe.total_ms = 0.0; }
+    for (auto& pe : c->prof_entries) { pe.launches = 0; pe.total_ms = 0.0; pe.dur_ms.clear(); pe.period_ms.clear(); }
     return DAVO_OK;
+}
+int davo_profile_samples(davo_ctx* c, const char* name, int which, float* out, int cap) {
+    if (!c || !name || which < 0 || which > 1 || cap < 0 || (cap > 0 && !out)) return DAVO_ERR_INVALID;
+    int rc = prof_collect(c);
+    if (rc) return rc;
+    for (const auto& pe : c->prof_entries)
+        if (pe.name == name) {
+            const std::vector<float>& v = which == 0 ? pe.dur_ms : pe.period_ms;
+            const int n = (int)std::min(v.size(), (size_t)cap);
+            for (int i = 0; i < n; ++i) out[i] = v[i];
+            return (int)v.size();
+        }
+    return 0;
 }
 int davo_profile_entry(davo_ctx* c, int i, char* name, int name_len, int* launches, double* total_ms) {
     if (!c) return DAVO_ERR_INVALID;
@@ -405,7 +518,7 @@ static int rebuild_slot_streams(davo_ctx* c, int n) {
     for (int i = 0; i < (int)c->slots.size(); ++i) {
         Slot& s = c->slots[i];
         if (s.stream) { HIP_TRY(c, hipStreamDestroy(s.stream)); s.stream = nullptr; }
-        if (c->cu_partition && n > 1 && i < n) {
+        if (c->cu_partition && n > 1 && i < n && c->dev_cus == 256) {          // the mask layout below is the 8 XCD x 32 CU part's
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const int lo = i * 32 / n, hi = (i + 1) * 32 / n;                 // CU indices inside an XCD
             for (int b = 0; b < 256; ++b)
@@ -416,7 +529,7 @@ static int rebuild_slot_streams(davo_ctx* c, int n) {
         }
     }
     c->own_stream = c->slots[0].stream;
-    c->ncu = (c->cu_partition && n > 1) ? 256 / n : 256;
+    c->ncu = (c->cu_partition && n > 1 && c->dev_cus == 256) ? 256 / n : c->dev_cus;
     activate_slot(c, 0);
     return DAVO_OK;
 }
@@ -433,7 +546,7 @@ int davo_set_inflight(davo_ctx* c, int n) {
     }
     c->inflight = n;
     c->next_slot = 0;
-    if (c->cu_partition || c->ncu != 256) { int rc = rebuild_slot_streams(c, n); if (rc) return rc; }
+    if (c->cu_partition || c->ncu != c->dev_cus) { int rc = rebuild_slot_streams(c, n); if (rc) return rc; }
     return DAVO_OK;
 }
 
@@ -446,6 +559,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "merge_rem") c->opt_merge_rem = value != 0;
     else if (k == "patch_cnv2") c->opt_patch_cnv2 = value != 0;
     else if (k == "patch_cnv3") c->opt_patch_cnv3 = value != 0;
+    else if (k == "auto_range") { int rc = judge_pending(c); if (rc) return rc; c->opt_auto_range = value != 0; }
     else if (k == "force_tile") {
         // test hook: every f16x3 layer the tile fits runs as ONE launch of that tile shape (plan.h tile ids; -1 = planner)
         if (value < -1 || value >= NUM_TILES) return fail(c, DAVO_ERR_INVALID, "force_tile must be -1..%d", NUM_TILES - 1);

@@ -38,8 +38,9 @@ static Rccl* rccl(std::string* why) {
     std::lock_guard<std::mutex> lock(mu);
     if (!tried) {
         tried = true;
-        std::string names[3] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", ""};
-        if (const char* rp = getenv("ROCM_PATH")) names[2] = std::string(rp) + "/lib/librccl.so.1";
+        // the loader's own search order (the library's rpath is /opt/rocm/lib, then LD_LIBRARY_PATH / ld.so.conf), then the
+        // image's fixed location; the library itself reads no environment variable
+        std::string names[2] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
         for (const auto& n : names) {
             if (n.empty()) continue;
             R.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);

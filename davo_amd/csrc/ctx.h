@@ -52,13 +52,25 @@ struct ProfEntry {
     int launches = 0;
     double total_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    // per-launch record since the last reset (davo_profile_samples; at most PROF_SAMPLES_CAP kept): the launch's own duration
+    // and the time from the previous bracketed launch's start to this one's (-1 when the previous start is not known)
+    std::vector<float> dur_ms, period_ms;
 };
+constexpr size_t PROF_SAMPLES_CAP = 8192;
 
 // One in-flight batch: its own HIP stream and activation workspace.  Weights are shared.
 struct Slot {
     hipStream_t stream = nullptr;
     float *d_partial = nullptr, *d_tab = nullptr, *d_packed = nullptr, *d_pose_partial = nullptr;
     float* d_act[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+// A batch davo_forward_device has issued and no verdict on its f16x3 range record has covered yet
+struct PendingBatch {
+    int B;
+    const void *img, *flow, *seg;
+    void* pose;
+    bool operator==(const PendingBatch& o) const { return B == o.B && img == o.img && flow == o.flow && seg == o.seg && pose == o.pose; }
 };
 
 struct Comm;                                     // comm.hip: RCCL communicator state
@@ -69,7 +81,8 @@ struct davo_ctx {
     int device = 0, H = 0, W = 0, max_batch = 0;
     std::vector<davo::Slot> slots;             // slots[0] is created by davo_create
     int inflight = 1, next_slot = 0;
-    int ncu = 256;                             // compute units a launch of this context may use (CU-masked slot streams: 256 / slots)
+    int dev_cus = 256;                         // compute units of the device (hipDeviceProp_t::multiProcessorCount, read by davo_create)
+    int ncu = 256;                             // compute units a launch of this context may use (CU-masked slot streams: dev_cus / slots)
     bool cu_partition = false;                 // davo_set_option "cu_partition": slot i's stream is masked to its own share of every XCD's CUs
     bool user_stream = false;
     bool opt_fuse_pose = true;                 // f16x3: pose head fused into cnv7's epilogue (davo_set_option)
@@ -117,6 +130,11 @@ struct davo_ctx {
     int act_shift[7] = {0, 0, 0, 0, 0, 0, 0};
     unsigned* d_range = nullptr;               // [8]
     bool range_dirty = false;                  // an f16x3 forward_device ran since the record was last checked
+    // Range recovery (davo_set_option "auto_range", default on): the device-path batches issued since the last verdict are
+    // remembered so that a failed verdict can re-issue them - recalibrated, or on the float32 kernels (api.hip: recover_batches)
+    bool opt_auto_range = true;
+    std::vector<davo::PendingBatch> pending;
+    long long n_recalibrations = 0, n_f32_batches = 0, n_reissued = 0;
     int host_chunk = 8;                        // davo_forward: windows per sub-batch (davo_set_option "host_chunk"; 0 = whole batch)
     // profiling
     bool prof = false;

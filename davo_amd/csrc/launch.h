@@ -24,6 +24,8 @@ hipError_t launch_layer(int layer, int BN, const ConvParams& p, dim3 grid, hipSt
 hipError_t launch_layer_h3(int layer, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s);
 // main launch (256x256 tiles, shared-tap staging) + remainder launch (128x128 tiles) of cnv5 / cnv6 (layer 4 / 5) as one grid
 // (conv_igemm_h3_mainrem); hipErrorNotSupported when the two launches do not have that shape: the caller issues them separately
+// whether launch_layer_h3_mainrem would issue this shape (asked BEFORE the profiling scope of the launch is opened)
+bool layer_h3_mainrem_supported(int layer, const ConvParamsH& pm, int n_main, int n_rem);
 hipError_t launch_layer_h3_mainrem(int layer, const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, hipStream_t s);
 // launch_h3s.hip: conv_igemm_h3s (TILE_208x256) for layer 4..6 = cnv5, cnv6, cnv7
 hipError_t launch_layer_h3s(int layer, const ConvParamsH& p, dim3 grid, hipStream_t s);

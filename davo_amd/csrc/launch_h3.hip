@@ -21,6 +21,17 @@ hipError_t launch_layer_h3(int layer, int tile, const ConvParamsH& p, dim3 grid,
 
 namespace {
 
+// the shared-tap instantiation's own conditions (launch_h3_impl.h, launch_m) and the grid shape the id order assumes
+template <int LAYER>
+bool mainrem_ok(const ConvParamsH& pm, int n_main, int n_rem) {
+    using namespace h3impl;
+    constexpr int RATE = layer_rate(LAYER);
+    if (!(pm.xs && pm.rate == RATE && pm.pad_l == RATE && pm.pad_t == RATE && pm.Hin == pm.Hout && pm.Win == pm.Wout &&
+          pm.nchunks % 3 == 0 && pm.Wout > 2 * RATE && pm.x_pix_log2 >= 7 && use_m16()))
+        return false;
+    return !(n_rem < 64 || n_rem % 64 || n_rem > 256 || n_main < n_rem / 2 || n_main % 8);
+}
+
 template <int LAYER>
 hipError_t launch_mainrem(const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, hipStream_t s) {
     using namespace h3impl;
@@ -29,11 +40,7 @@ hipError_t launch_mainrem(const ConvParamsH& pm, int n_main, const ConvParamsH& 
     using TX = TileX<4, 2, 2, 4, 2, RATE>;
     using TR = TileH<4, 2, 1, 2, DAVO_REM_STAGES>;
     static_assert(DAVO_REM_STAGES == 3, "conv_igemm_h3_mainrem instantiates the three-slot remainder tile");
-    // the shared-tap instantiation's own conditions (launch_h3_impl.h, launch_m) and the grid shape the id order assumes
-    if (!(pm.xs && pm.rate == RATE && pm.pad_l == RATE && pm.pad_t == RATE && pm.Hin == pm.Hout && pm.Win == pm.Wout &&
-          pm.nchunks % 3 == 0 && pm.Wout > 2 * RATE && pm.x_pix_log2 >= 7 && use_m16()))
-        return hipErrorNotSupported;
-    if (n_rem < 64 || n_rem % 64 || n_rem > 256 || n_main < n_rem / 2 || n_main % 8) return hipErrorNotSupported;
+    if (!mainrem_ok<LAYER>(pm, n_main, n_rem)) return hipErrorNotSupported;
     constexpr int lds = TX::LDS_BYTES > TR::LDS_BYTES_DMA ? TX::LDS_BYTES : TR::LDS_BYTES_DMA;
     auto kern = conv_igemm_h3_mainrem<LAYER, RATE>;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
@@ -43,6 +50,12 @@ hipError_t launch_mainrem(const ConvParamsH& pm, int n_main, const ConvParamsH& 
 }
 
 }  // namespace
+
+bool layer_h3_mainrem_supported(int layer, const ConvParamsH& pm, int n_main, int n_rem) {
+    if (layer == 4) return mainrem_ok<5>(pm, n_main, n_rem);
+    if (layer == 5) return mainrem_ok<6>(pm, n_main, n_rem);
+    return false;
+}
 
 hipError_t launch_layer_h3_mainrem(int layer, const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, hipStream_t s) {
     if (layer == 4) return launch_mainrem<5>(pm, n_main, pr, n_rem, s);

@@ -20,8 +20,9 @@ class DavoError(RuntimeError):
 
 
 class DavoRangeError(DavoError):
-    """f16x3: a layer's activations left the fp16-pair storage range (include/davo_hip.h: DAVO_ERR_RANGE);
-    Engine.calibrate(...) or Engine.set_precision('f32') resolves it."""
+    """f16x3: a layer's activations left the fp16-pair storage range (include/davo_hip.h: DAVO_ERR_RANGE).
+    Only raised with ``set_option("auto_range", 0)``: by default the library re-issues such a batch itself
+    (re-calibrated, or on its float32 kernels), as the reference's float32 graph never fails on a finite network."""
 
 
 _PY_ERR = {-1: ValueError, -2: DavoError, -3: DavoError, -4: MemoryError, -5: DavoRangeError}
@@ -160,6 +161,13 @@ class Engine:
         self._check(self._L.davo_activation_range(self._ctx, mx, sh, int(bool(reset))))
         return dict(zip(self.LAYERS, list(mx))), dict(zip(self.LAYERS, list(sh)))
 
+    def range_stats(self):
+        """{'recalibrations', 'f32_batches', 'reissued'}: what the f16x3 range recovery has done so far
+        (include/davo_hip.h: davo_range_stats)."""
+        a, b, c = ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+        self._check(self._L.davo_range_stats(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"recalibrations": a.value, "f32_batches": b.value, "reissued": c.value}
+
     def set_activation_shifts(self, shifts=None):
         """Install storage scales from an earlier calibrate() (dict or sequence of 6 ints; None = none)."""
         if shifts is None:
@@ -181,7 +189,8 @@ class Engine:
         self._check(self._L.davo_synchronize(self._ctx))
 
     def set_option(self, key, value):
-        """'fuse_pose' (default 1), 'fuse_pack' (default 0), 'host_chunk' (default 8): see include/davo_hip.h."""
+        """'auto_range' (default 1), 'fuse_pose' (default 1), 'fuse_pack' (default 0), 'host_chunk' (default 8), ...:
+        see include/davo_hip.h."""
         self._check(self._L.davo_set_option(self._ctx, key.encode(), int(value)))
 
     def set_inflight(self, n):
@@ -210,6 +219,18 @@ class Engine:
             out[name.value.decode()] = (n.value, ms.value)
             i += 1
         return out
+
+    def profile_samples(self, name, cap=8192):
+        """(durations_ms, periods_ms) of every bracketed launch of `name` since the last profile_reset, in issue order
+        (include/davo_hip.h: davo_profile_samples); period = start of the previous bracketed launch to this one's start."""
+        out = []
+        for which in (0, 1):
+            buf = (ctypes.c_float * cap)()
+            n = self._L.davo_profile_samples(self._ctx, name.encode(), which, buf, cap)
+            if n < 0:
+                self._check(n)
+            out.append(np.array(buf[:min(n, cap)], np.float32))
+        return out[0], out[1]
 
     def last_plan(self, layer):
         """[(mtiles, BN), ...] of the launches the last forward used for conv layer 0..6."""
@@ -286,8 +307,9 @@ class DAVO(object):
             self.engine.load_weights(weights)
 
     def calibrate(self, inputs):
-        """Range-calibrate the f16x3 arithmetic on a sample batch (img, flow, seg); see Engine.calibrate.  The
-        reference's float32 graph has no counterpart; a checkpoint whose activations sit far from O(1) needs it."""
+        """Range-calibrate the f16x3 arithmetic on a sample batch (img, flow, seg); see Engine.calibrate.  Optional:
+        ``inference`` re-calibrates by itself on the first batch that leaves the range (the reference's float32
+        graph has no counterpart and never fails, davo.py:1553-1569); calling it up front only saves that re-issue."""
         if self.engine is None:
             raise DavoError("setup_inference(..., mode='davo') has not been called")
         return self.engine.calibrate(*inputs)

@@ -7,8 +7,15 @@ its place the same way) and a fresh ``DAVO_COMM_DIR`` for the RCCL id (davo_amd/
 parent only waits: it returns the first non-zero exit code and stops the remaining ranks, so a failed
 rank fails the run (no rank is left waiting in a collective).  Nothing here imports the HIP library
 or initialises a device — a process that has done so must not be replaced or forked into ranks.
+
+Each rank is bound to its own contiguous slice of the CPUs this process may use (``sched_getaffinity``), so the
+ranks' loader / decode threads do not migrate over each other's cores (and stay on one NUMA side where the
+allowed set spans several).  ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is passed on (and defaulted) because RCCL shares device
+buffers between the ranks' processes through HIP IPC handles, and the hosts' driver only supports the dmabuf form of
+them: with the legacy mode ``ncclCommInitRank`` fails in ``hipIpcGetMemHandle: invalid argument``.
 """
 import os
+import secrets
 import shutil
 import signal
 import subprocess
@@ -17,19 +24,37 @@ import tempfile
 import time
 
 
-def spawn_ranks(argv, nprocs, env_extra=None, timeout=None):
-    """Run ``sys.executable argv...`` as ``nprocs`` ranks; -> exit code (0 only if every rank returned 0)."""
-    comm_dir = tempfile.mkdtemp(prefix="davo_comm_")
+def cpu_slices(nprocs, cpus=None):
+    """the allowed CPUs cut into nprocs contiguous slices (rank r gets slice r); fewer CPUs than ranks: everyone keeps all"""
+    cpus = sorted(os.sched_getaffinity(0) if cpus is None else cpus)
+    if len(cpus) < nprocs:
+        return [set(cpus)] * nprocs
+    return [set(cpus[r * len(cpus) // nprocs:(r + 1) * len(cpus) // nprocs]) for r in range(nprocs)]
+
+
+def spawn_ranks(argv, nprocs, env_extra=None, timeout=None, bind_cpus=True, stdout=None):
+    """Run ``sys.executable argv...`` as ``nprocs`` ranks; -> exit code (0 only if every rank returned 0).
+    ``stdout``: a file the ranks' standard output goes to instead of this process's."""
+    comm_dir = tempfile.mkdtemp(prefix="davo_comm_")        # 0700, this run's alone
+    nonce = secrets.token_hex(8)                             # the id file's name is not predictable either
+    slices = cpu_slices(nprocs) if bind_cpus and nprocs > 1 else None
     procs = []
     try:
         for r in range(nprocs):
             env = dict(os.environ)
             env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nprocs), "LOCAL_WORLD_SIZE": str(nprocs),
-                        "DAVO_COMM_DIR": comm_dir, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                        "DAVO_COMM_DIR": comm_dir, "DAVO_COMM_NONCE": nonce,
+                        "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
             env.setdefault("MASTER_ADDR", "127.0.0.1")
             if env_extra:
                 env.update(env_extra)
-            procs.append(subprocess.Popen([sys.executable] + list(argv), env=env))
+            p = subprocess.Popen([sys.executable] + list(argv), env=env, stdout=stdout)
+            if slices is not None:
+                try:
+                    os.sched_setaffinity(p.pid, slices[r])  # before the rank has started any thread of its own
+                except OSError:
+                    pass
+            procs.append(p)
         t0 = time.time()
         code = 0
         live = list(procs)

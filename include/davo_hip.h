@@ -77,10 +77,14 @@ int davo_forward(davo_ctx* ctx, int B, const uint8_t* img, const float* flow, co
 /* Same computation on device-resident buffers (the path bench.py times; multi-GPU shards keep
  * their windows in HBM).  Asynchronous on the context's stream unless elapsed_ms != NULL, in
  * which case it is bracketed by HIP events, synchronised, and the device time is returned.
+ * With davo_set_inflight(ctx, n > 1) the timed form still waits for its own batch only and the
+ * batches of all slots are judged together at davo_synchronize().
  * f16x3 range guard: the asynchronous form cannot know its own result, so the batches issued
- * since the last davo_synchronize() are judged there (DAVO_ERR_RANGE from davo_synchronize means
- * one of them left the fp16-pair storage range: see davo_calibrate); the timed, synchronous form
- * returns DAVO_ERR_RANGE itself. */
+ * since the last davo_synchronize() get their verdict there.  A failed verdict RE-ISSUES those
+ * batches (see "auto_range" below), so the caller must keep the input and output buffers of every
+ * batch alive and unchanged until davo_synchronize() has returned — which it has to anyway to
+ * read the poses.  The timed, synchronous form judges (and re-issues) its own batch; elapsed_ms is
+ * then the first issue's time. */
 int davo_forward_device(davo_ctx* ctx, int B, const void* d_img, const void* d_flow,
                         const void* d_seg, void* d_pose, float* elapsed_ms);
 
@@ -97,10 +101,12 @@ int davo_host_alloc(int device, size_t bytes, void** out);
 int davo_host_free(void* p);
 int davo_memcpy_h2d(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
 int davo_memcpy_d2h(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
-/* Waits for every stream of the context.  Returns DAVO_ERR_RANGE if an f16x3 batch issued through
- * davo_forward_device since the previous call left the fp16-pair storage range (poses of those
- * batches are not float32-grade; the next batch starts a fresh record, so the next call judges later
- * batches only). */
+/* Waits for every stream of the context, then gives the f16x3 batches issued through
+ * davo_forward_device since the previous call their range verdict.  If one of them left the fp16-pair
+ * storage range, all of them are re-issued before the call returns (re-calibrated, or on the float32
+ * kernels: "auto_range"), so on DAVO_OK every pose buffer holds float32-grade results.  With
+ * "auto_range" 0 the failed verdict is returned as DAVO_ERR_RANGE instead (the poses of those batches are
+ * not float32-grade; the next batch starts a fresh record). */
 int davo_synchronize(davo_ctx* ctx);
 /* Run on a caller-owned hipStream_t (NULL restores the context's own stream). */
 int davo_set_stream(davo_ctx* ctx, void* hip_stream);
@@ -121,6 +127,11 @@ int davo_profile_enable(davo_ctx* ctx, int on);   /* 0 off | 1 every kernel | 2 
 int davo_profile_reset(davo_ctx* ctx);
 int davo_profile_entry(davo_ctx* ctx, int i, char* name, int name_len, int* launches,
                        double* total_ms);
+/* Per-launch record of one label since the last reset, in issue order: which = 0 the launches' own durations (ms),
+ * which = 1 the time from the previous bracketed launch's START to this one's (with every batch bracketed, one step's
+ * period on the stream; -1 for the first sample).  Copies up to cap floats, returns the number recorded (>= 0) or a
+ * negative davo_status.  bench.py reports the clock ramp of its timed region from it. */
+int davo_profile_samples(davo_ctx* ctx, const char* name, int which, float* out, int cap);
 
 /* How the LAST forward issued conv layer `layer` (0..6 = cnv1..cnv7): launch 0 is the main launch,
  * launch 1 the remainder launch with a narrower N tile (mtiles = 0 if there was none).  A launch
@@ -138,8 +149,13 @@ int davo_set_precision(davo_ctx* ctx, int precision);
 
 /* f16x3 range management.  Activations between layers are stored as fp16 (hi, lo) pairs; a layer's values must
  * stay below 65504 (they are clamped there) and its largest value above ~2^-11 for the pairs to carry float32-grade
- * precision.  Each storing kernel records the largest value it wrote; davo_forward checks the record of its own call
- * and returns DAVO_ERR_RANGE (poses are still written) if a layer left the range.  davo_calibrate runs the path on
+ * precision.  Each storing kernel records the largest value it wrote; davo_forward checks the record of its own call.
+ * The reference's float32 graph never fails on a finite network (davo.py:1553-1569), so by default neither does this
+ * library: a batch that left the range is re-issued with the scales re-calibrated ON THAT BATCH, and if it still
+ * leaves the range (no per-layer power of two covers it) on the float32 kernels — mode 0 below, for that batch only;
+ * later batches run f16x3 with the new scales.  davo_range_stats counts what happened.  davo_set_option(ctx,
+ * "auto_range", 0) turns the recovery off: the entry points then return DAVO_ERR_RANGE (poses are still written, not
+ * float32-grade) and the caller calibrates or changes mode itself.  davo_calibrate runs the path on
  * a sample batch (device buffers, as davo_forward_device) and gives every layer an exact power-of-two storage
  * scale that puts its largest value in [512, 1024); results inside the safe range do not depend on the scales
  * beyond rounding noise (~1e-8).  The reference's float32 graph needs none of this (TF conv2d, nets/posenn.py:205-215);
@@ -150,8 +166,14 @@ int davo_set_precision(davo_ctx* ctx, int precision);
 int davo_calibrate(davo_ctx* ctx, int batch, const void* d_img, const void* d_flow, const void* d_seg, int* shifts_out);
 int davo_activation_range(davo_ctx* ctx, float* max_abs, int* shifts, int reset);
 int davo_set_activation_shifts(davo_ctx* ctx, const int* shifts);
+/* Range recoveries since davo_create: re-calibrations triggered by a failed verdict, batches that ran on the float32
+ * kernels because no scale covered them, batches re-issued in total.  Any pointer may be NULL. */
+int davo_range_stats(davo_ctx* ctx, long long* recalibrations, long long* f32_batches, long long* reissued);
 
-/* Kernel-fusion switches of the f16x3 path (both modes give the same poses to ~1e-7):
+/* Options.
+ *   "auto_range" (default 1): f16x3 batches that leave the fp16-pair storage range are re-issued (see above); 0 = the
+ *       failed verdict is returned as DAVO_ERR_RANGE.
+ * Kernel-fusion switches of the f16x3 path (both modes give the same poses to ~1e-7):
  *   "fuse_pose" (default 1): pred 1x1 + spatial mean + 0.01 (nets/posenn.py:240-250) run in cnv7's
  *       epilogue; the cnv7 activation is never written to HBM.  0 = cnv7 stored, separate pose-head kernels.
  *   "fuse_pack" (default 0): cnv1 builds its input patch from the raw inputs (mask + pack fused in).

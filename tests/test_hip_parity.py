@@ -323,14 +323,15 @@ def _rescaled(weights, shift):
 @pytest.mark.parametrize("shift", [-22, 16])
 def test_range_guard_and_calibration(c_oracle, shift):
     """A checkpoint whose cnv3 activations are ~2^-22 (fp16 pairs lose their bits) or ~2^16 (beyond the fp16
-    maximum): the host entry point refuses loudly (DAVO_ERR_RANGE), calibrate() moves the layer's storage scale,
-    and the poses then meet the bar like any other checkpoint."""
+    maximum), with the automatic recovery switched off: the host entry point refuses loudly (DAVO_ERR_RANGE),
+    calibrate() moves the layer's storage scale, and the poses then meet the bar like any other checkpoint."""
     from davo_amd import DavoRangeError
     cfg = parse_version(FLAGSHIP_VERSION)
     img, flow, seg = synth.make_inputs(2, 64, 96)
     weights = synth.make_weights(cfg)
     want = c_oracle.forward(cfg, img, flow, seg, weights)
     e = _engine(cfg, 64, 96, 2, _rescaled(weights, shift), "f16x3")
+    e.set_option("auto_range", 0)                                         # the plain verdict, no recovery
     with pytest.raises(DavoRangeError, match="cnv3 activations"):
         e.forward(img, flow, seg)
     shifts = e.calibrate(img, flow, seg)
@@ -553,6 +554,7 @@ def test_device_path_range_guard_at_synchronize(c_oracle, shift):
     img, flow, seg = synth.make_inputs(B, 64, 96)
     weights = synth.make_weights(cfg)
     e = _engine(cfg, 64, 96, B, _rescaled(weights, shift), "f16x3")
+    e.set_option("auto_range", 0)                            # the plain verdict, no recovery
     bufs = (e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48))
     e.forward_device(B, *bufs)
     with pytest.raises(DavoRangeError, match="cnv3 activations"):
@@ -877,3 +879,211 @@ def test_shared_tap_staging_is_bit_identical(c_oracle, B, H, W):
         assert np.array_equal(got, base)
     assert_pose_close(got, c_oracle.forward(cfg, img, flow, seg, weights), "shared taps")
     e.close()
+
+
+# ---- f16x3 at the reference's call surface: never an error on a finite float32 network (davo.py:1553-1569) ----------
+def _scale_channels(weights, producer, consumers, idx, shift):
+    """ReLU homogeneity per channel: output channels `idx` of `producer` (weights + bias) x 2^shift and the matching input
+    channels of every consumer x 2^-shift is the same network with those activation channels scaled by 2^shift."""
+    k = np.float32(2.0 ** shift)
+    w2 = dict(weights)
+    pw = weights["pose_exp_net/%s/weights" % producer].copy()
+    pb = weights["pose_exp_net/%s/biases" % producer].copy()
+    pw[..., idx] *= k
+    pb[idx] *= k
+    w2["pose_exp_net/%s/weights" % producer], w2["pose_exp_net/%s/biases" % producer] = pw, pb
+    for cons in consumers:
+        cw = weights["pose_exp_net/%s/weights" % cons].copy()
+        cw[:, :, idx, :] /= k
+        w2["pose_exp_net/%s/weights" % cons] = cw
+    return w2
+
+
+@pytest.mark.parametrize("shift", [-22, 16])
+def test_auto_range_host_path_never_raises(c_oracle, shift):
+    """The checkpoints of test_range_guard_and_calibration through the DEFAULT engine: the first batch leaves the
+    fp16-pair range, the library re-calibrates on it and re-issues it; the caller sees float32-grade poses, no error."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(2, 64, 96)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    e = _engine(cfg, 64, 96, 2, _rescaled(weights, shift), "f16x3")
+    assert_pose_close(e.forward(img, flow, seg), want, "auto range, cnv3 x 2^%d" % shift)
+    st = e.range_stats()
+    assert st == {"recalibrations": 1, "f32_batches": 0, "reissued": 1}, st
+    assert_pose_close(e.forward(img, flow, seg), want, "second batch, new scales")
+    assert e.range_stats() == st                                          # the new scales hold: nothing re-issued
+    e.close()
+    d = DAVO(version=FLAGSHIP_VERSION)                                    # and through the reference's call surface
+    d.load_weights(_rescaled(weights, shift))
+    d.setup_inference(64, 96, "davo", 3, 2, img, None, flow, None, seg)
+    assert_pose_close(d.inference(None, "pose")["pose"], want, "DAVO.inference, cnv3 x 2^%d" % shift)
+    d.engine.close()
+
+
+def test_auto_range_device_path_reissues_at_synchronize(c_oracle):
+    """Asynchronous batches on two buffer sets, three in flight before the verdict: synchronize() re-issues them and
+    returns with every pose buffer float32-grade."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B = 2
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, 64, 96, B, _rescaled(weights, 16), "f16x3")
+    sets, wants = [], []
+    for k in range(2):
+        img, flow, seg = synth.make_inputs(B, 64, 96, first_window=5 * k)
+        sets.append((e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48)))
+        wants.append(c_oracle.forward(cfg, img, flow, seg, weights))
+    for k in (0, 1, 0):
+        e.forward_device(B, *sets[k])
+    e.synchronize()
+    for k in range(2):
+        assert_pose_close(sets[k][3].download((B, 2, 6)), wants[k], "device path, set %d" % k)
+    st = e.range_stats()
+    assert st["reissued"] == 2 and st["recalibrations"] >= 1 and st["f32_batches"] == 0, st     # two distinct batches, each once
+    for k in (0, 1):
+        e.forward_device(B, *sets[k])
+    e.synchronize()
+    assert e.range_stats() == st
+    assert e.forward_device(B, *sets[0], timed=True) > 0.0
+    e.close()
+
+
+def test_auto_range_falls_back_to_the_f32_kernels(c_oracle):
+    """cnv3 activations at 2^-80: no storage scale in [-60, 60] brings them into the fp16-pair range, so the batch runs
+    on the library's own float32 kernels (never the oracle) and still meets the bar."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(2, 64, 96)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    e = _engine(cfg, 64, 96, 2, _rescaled(weights, -80), "f16x3")
+    assert_pose_close(e.forward(img, flow, seg), want, "f32 fallback")
+    st = e.range_stats()
+    assert st["f32_batches"] == 1 and st["reissued"] == 1, st
+    e.close()
+
+
+@pytest.mark.parametrize("H,W,B", [(64, 96, 2), (128, 416, 1)])
+def test_per_channel_dynamic_range(c_oracle, H, W, B):
+    """Wide dynamic range INSIDE a layer: every other output channel of cnv3 and of cnv5 carries 2^-10 of its
+    neighbours' magnitude (the next layer's matching input-channel weights x 2^10: the same network).  One power-of-two
+    scale per layer cannot lift those channels, so their hi/lo pairs sit 10 bits lower in the fp16 range; the bar must
+    hold with and without calibration (the bound)."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(B, H, W)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    w2 = _scale_channels(weights, "cnv3", ["cnv4"], np.arange(0, 64, 2), -10)
+    w2 = _scale_channels(w2, "cnv5", ["pose/rotation/cnv6", "pose/translation/cnv6"], np.arange(1, 256, 2), -10)
+    assert_pose_close(c_oracle.forward(cfg, img, flow, seg, w2), want, "oracle: the rescaled net is the same net")
+    for precision in PRECISIONS:
+        e = _engine(cfg, H, W, B, w2, precision)
+        assert_pose_close(e.forward(img, flow, seg), want, "per-channel 2^-10, %s" % precision)
+        if precision == "f16x3":
+            e.calibrate(img, flow, seg)
+            assert_pose_close(e.forward(img, flow, seg), want, "per-channel 2^-10, calibrated")
+            assert e.range_stats()["reissued"] == 0
+        e.close()
+
+
+def test_heavy_tailed_weights(c_oracle):
+    """A few weights per layer 100x larger than the rest (the layer's power-of-two weight scale is set by them, the
+    ordinary weights' lo halves sit 7 bits lower): another network, so the oracle runs on the same weights."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(2, 64, 96)
+    weights = dict(synth.make_weights(cfg))
+    rng = np.random.RandomState(7)
+    for name in list(weights):
+        if name.endswith("/weights") and "/pred/" not in name:
+            w = weights[name].copy()
+            flat = w.reshape(-1)
+            idx = rng.choice(flat.size, 6, replace=False)
+            flat[idx] *= 100.0
+            weights[name] = w
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    assert np.isfinite(want).all() and np.abs(want).max() > 1e-2
+    for precision in PRECISIONS:
+        e = _engine(cfg, 64, 96, 2, weights, precision)
+        assert_pose_close(e.forward(img, flow, seg), want, "heavy-tailed weights, %s" % precision)
+        e.close()
+
+
+def test_later_windows_louder_than_the_calibration_window(c_oracle):
+    """A sequence through DAVO.inference (iterator inputs, davo.py:1553-1569) whose windows 3.. carry 2^8 larger flow
+    than the window the scales were calibrated on: the loud batch is re-calibrated and re-issued inside the call, the
+    windows after it run on the new scales, every pose meets the bar."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    H, W, B, nb = 64, 96, 1, 6
+    weights = synth.make_weights(cfg)
+    batches = []
+    for i in range(nb):
+        img, flow, seg = synth.make_inputs(B, H, W, first_window=i)
+        if i >= 3:
+            flow = (flow * np.float32(256.0)).astype(np.float32)
+        batches.append((img, flow, seg))
+    d = DAVO(version=FLAGSHIP_VERSION)
+    d.load_weights(weights)
+    d.setup_inference(H, W, "davo", 3, B, iter(batches))
+    d.calibrate(batches[0])
+    for i in range(nb):
+        got = d.inference(None, "pose")["pose"]
+        assert_pose_close(got, c_oracle.forward(cfg, *batches[i], weights), "window %d" % i)
+    st = d.engine.range_stats()
+    assert st["recalibrations"] == 1 and st["reissued"] == 1 and st["f32_batches"] == 0, st
+    d.engine.close()
+
+
+@pytest.mark.parametrize("B", [11, 32])
+def test_profile_counts_one_launch_per_forward(B):
+    """Every profiled layer records exactly one event pair per forward (per issued launch), also at a batch where the
+    merged cnv5 / cnv6 grid does not apply and the layer falls back to main + remainder launches (B = 11)."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    H, W = 128, 416
+    img, flow, seg = synth.make_inputs(1, H, W)
+    img, flow, seg = (np.repeat(a, B, axis=0) for a in (img, flow, seg))
+    e = _engine(cfg, H, W, B, synth.make_weights(cfg), "f16x3")
+    bufs = (e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48))
+    e.forward_device(B, *bufs)
+    e.synchronize()
+    n = 4
+    e.profile(1)
+    e.profile_reset()
+    for _ in range(n):
+        e.forward_device(B, *bufs)
+    ent = e.profile_entries()
+    for layer in ("cnv5", "cnv6"):
+        launches = len(e.last_plan({"cnv5": 4, "cnv6": 5}[layer]))
+        assert ent[layer][0] == n and ent[layer][1] > 0.0, (layer, ent)
+        assert (layer + ".rem" in ent) == (launches == 2), (layer, launches, sorted(ent))
+        if launches == 2:
+            assert ent[layer + ".rem"][0] == n
+    e.profile(2)
+    e.set_option("profile_stride", 2)
+    e.profile_reset()
+    for _ in range(n):
+        e.forward_device(B, *bufs)
+    ent = e.profile_entries()
+    assert ent["cnv6"][0] == n // 2 and ent["cnv6"][1] > 0.0, ent
+    e.profile(False)
+    e.close()
+
+
+def test_bench_multi_gpu_code_path_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path (RCCL communicator, barrier-bracketed timed region, max all-reduce over ranks, pose
+    all-gather) executed at world size 1 through the rank launcher: `--force-comm`.  The driver's 8-GPU run then is not
+    the first execution of that code."""
+    import json
+    import sys
+    from davo_amd.launch import spawn_ranks
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "bench.out"
+    with open(out, "wb") as f:
+        rc = spawn_ranks([os.path.join(root, "bench.py"), "--gpus", "1", "--force-comm", "--steps", "3", "--warmup", "1", "--settle", "2",
+                          "--batch", "4", "--no-cpu-baseline", "--no-f32", "--no-pipelined"], 1, stdout=f, timeout=600)
+    assert rc == 0
+    res = json.loads(open(out).read().strip().splitlines()[-1])
+    g = res["gather"]
+    assert g and g["ranks"] == 1 and g["forced_at_world_1"] and g["bytes_per_rank"] == 4 * 48 and g["collective_ms"] >= 0.0
+    assert res["n_gpus"] == 1 and res["steps"] == 3 and res["value"] > 0 and res["timing"]["settle_steps"] == 2
+    assert res["timing"]["dominant_launch_ms"]["n"] == 3 and res["timing"]["step_ms_on_stream"]["n"] == 2
+    assert res["max_abs_err_vs_oracle"] <= 1e-4 * res["max_abs_ref"]
+    assert res["config"]["workload"].startswith("none of BASELINE.json's configs")

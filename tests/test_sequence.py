@@ -3,6 +3,7 @@
 tests/golden/kitti_gt_poses_03.txt is a DATA fixture: the KITTI ground-truth poses of sequence 03
 that the reference ships under kitti_benchmark/data/odometry/poses/03.txt (801 lines x 12 floats)."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -168,7 +169,10 @@ _CHILD = """
 import os, sys
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.path.isdir(os.environ["DAVO_COMM_DIR"])
+assert len(os.environ["DAVO_COMM_NONCE"]) == 16 and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+cpus = ",".join(str(c) for c in sorted(os.sched_getaffinity(0)))
 open(os.path.join(sys.argv[1], "rank%d" % rank), "w").write(os.environ["DAVO_COMM_DIR"])
+open(os.path.join(sys.argv[1], "cpus%d" % rank), "w").write(cpus)
 sys.exit(int(sys.argv[2]) if rank == int(sys.argv[3]) else 0)
 """
 
@@ -180,6 +184,15 @@ def test_spawn_ranks_sets_the_launch_contract_and_fails_if_any_rank_fails(tmp_pa
     assert spawn_ranks([str(script), str(tmp_path), "0", "0"], 3) == 0
     dirs = {open(tmp_path / ("rank%d" % r)).read() for r in range(3)}
     assert len(dirs) == 1 and not os.path.exists(dirs.pop())          # one fresh rendezvous directory, removed afterwards
+    # every rank is bound to its own slice of the CPUs the parent may use (the slices partition them, in order)
+    from davo_amd.launch import cpu_slices
+    want = cpu_slices(3)
+    got = [set(int(c) for c in open(tmp_path / ("cpus%d" % r)).read().split(",")) for r in range(3)]
+    assert got == want, (got, want)
+    if len(os.sched_getaffinity(0)) >= 3:
+        assert set().union(*got) == set(os.sched_getaffinity(0)) and sum(len(g) for g in got) == len(os.sched_getaffinity(0))
+    assert cpu_slices(4, cpus=range(10)) == [{0, 1}, {2, 3, 4}, {5, 6}, {7, 8, 9}]
+    assert cpu_slices(3, cpus=[5, 9]) == [{5, 9}] * 3                   # fewer CPUs than ranks: nobody is pinned
     assert spawn_ranks([str(script), str(tmp_path), "7", "1"], 3) == 7  # rank 1 exits 7 -> the run is a failure
 
 
@@ -199,12 +212,44 @@ def test_comm_rendezvous_path_prefers_the_launcher_directory(monkeypatch, tmp_pa
     monkeypatch.delenv("DAVO_COMM_FILE", raising=False)
     monkeypatch.setenv("DAVO_COMM_DIR", str(tmp_path))
     assert comm.rendezvous_path() == str(tmp_path / "rccl_id")
+    monkeypatch.setenv("DAVO_COMM_NONCE", "00ff")
+    assert comm.rendezvous_path() == str(tmp_path / "rccl_id.00ff")      # spawn_ranks: a per-launch nonce in the name
     monkeypatch.delenv("DAVO_COMM_DIR")
     monkeypatch.setenv("MASTER_PORT", "29511")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job/7")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
     p = comm.rendezvous_path()
     assert str(os.getppid()) in p and "29511" in p           # ranks of one torch.distributed.run share parent and port
+    d = os.path.dirname(p)
+    st = os.stat(d)
+    assert st.st_uid == os.getuid() and (st.st_mode & 0o777) == 0o700     # private per-user directory
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    assert comm.rendezvous_path() != p                       # a restarted worker group never reads its predecessor's id
     monkeypatch.setenv("DAVO_COMM_FILE", "/x/y")
     assert comm.rendezvous_path() == "/x/y"
+
+
+def test_comm_id_file_from_before_the_launcher_is_stale(tmp_path):
+    """A reader accepts an id file only if it was written under its own launcher: the test for it is the launcher
+    process's start time (this test's parent), so a file dated before that is never read."""
+    from davo_amd import comm
+    t = comm._launcher_start_time()
+    assert 0 < t <= time.time()
+    f = tmp_path / "rccl_id"
+    f.write_bytes(b"x" * 128)
+    os.utime(f, (t - 5, t - 5))
+    assert os.stat(f).st_mtime < t                           # what RcclComm's reader loop compares
+
+
+def test_bench_names_the_config_its_arguments_select():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(HERE), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.workload_name(32, 128, 416, 1).startswith("BASELINE.json configs[1]")
+    assert b.workload_name(128, 128, 416, 1).startswith("BASELINE.json configs[2]")
+    assert b.workload_name(64, 256, 832, 8).startswith("BASELINE.json configs[4]")
+    assert b.workload_name(11, 128, 416, 1).startswith("none of BASELINE.json's configs")
 
 
 # ---- row f1 pinned to reference-held code and fixtures ---------------------------------------------------

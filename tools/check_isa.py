@@ -68,18 +68,28 @@ def check_patch_loops(path):
     return n_kernels, problems
 
 
-def check(path):
+KINDS = ("conv_igemm_h3", "conv_igemm_h3_mainrem", "conv_igemm_h3s")
+
+
+def check(path, kinds=None):
+    """-> (kernels checked, chunk bodies checked, problems); `kinds` (a dict) receives the kernel count per kernel family:
+    conv_igemm_h3 (16x16x32 instantiations only), conv_igemm_h3_mainrem (the merged cnv5 / cnv6 grid: both tile bodies are
+    16x16x32) and conv_igemm_h3s (the 208x256 tile, its own counted lgkmcnt / vmcnt waits)."""
     name, in_chunk, saw_barrier, n_chunks, n_kernels, problems, pending = None, False, False, 0, 0, [], []
     mfma_in_chunk = 0
     for line in open(path):
-        m = re.match(r"^(_ZN4davo13conv_igemm_h3\w+):", line)
+        m = re.match(r"^(_ZN4davo(?:13(conv_igemm_h3)I|21(conv_igemm_h3_mainrem)I|14(conv_igemm_h3s)I)\w+):", line)
         if m:
             name, in_chunk, saw_barrier = m.group(1), False, False
-            m16 = re.search(r"Lb1ELb[01]ELb1ELi\dELi\dEEEvNS", name) is not None   # <..., DMA=true, SMALLC, M16=true, NSTG, RATE>
+            kind = m.group(2) or m.group(3) or m.group(4)
+            # conv_igemm_h3<..., DMA=true, SMALLC, M16=true, NSTG, RATE>: only the 16x16x32 form has the hand-counted loop
+            m16 = kind != "conv_igemm_h3" or re.search(r"Lb1ELb[01]ELb1ELi\dELi\dEEEvNS", name) is not None
             if not m16:
                 name = None
             else:
                 n_kernels += 1
+                if kinds is not None:
+                    kinds[kind] = kinds.get(kind, 0) + 1
             continue
         if name is None:
             continue
@@ -107,14 +117,22 @@ def check(path):
 
 
 def main():
+    kinds = {}
     if len(sys.argv) > 1:
-        nk, nc, problems = check(sys.argv[1])
+        nk, nc, problems = check(sys.argv[1], kinds)
     else:
+        nk, nc, problems = 0, 0, []
         with tempfile.TemporaryDirectory() as d:
-            out = os.path.join(d, "launch_h3.s")
-            compile_to_asm(out)
-            nk, nc, problems = check(out)
-    print("%d 16x16x32 kernels, %d chunk bodies checked, %d problem(s)" % (nk, nc, len(problems)))
+            for unit in ("launch_h3.hip", "launch_h3s.hip"):          # the merged grid lives in launch_h3.hip, the 208x256 tile in its own unit
+                out = os.path.join(d, unit.replace(".hip", ".s"))
+                compile_to_asm(out, unit)
+                k, c, pr = check(out, kinds)
+                nk, nc, problems = nk + k, nc + c, problems + pr
+        for kind in KINDS:                                            # a family the name pattern no longer matches is a hole, not a pass
+            if not kinds.get(kind):
+                problems.append("no %s kernel found: the guard does not see that kernel family" % kind)
+    print("%d hand-scheduled kernels (%s), %d chunk bodies checked, %d problem(s)" %
+          (nk, ", ".join("%s: %d" % (k, kinds.get(k, 0)) for k in KINDS), nc, len(problems)))
     for p in problems[:20]:
         print("  " + p)
     npk, pprob = 1, []

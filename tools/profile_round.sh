@@ -18,7 +18,7 @@ python3 "$R/bench.py" > "$O/bench_${TAG}32.json" 2> "$O/bench_${TAG}32.err"; ech
 python3 "$R/bench.py" --batch 128 --no-cpu-baseline > "$O/bench_${TAG}128.json" 2>/dev/null
 python3 "$R/bench.py" --height 256 --width 832 --batch 64 --no-cpu-baseline > "$O/bench_${TAG}64_256x832.json" 2>/dev/null
 for f in 32 128 64_256x832; do
-  python3 -c "import json; d=json.loads(open('$O/bench_${TAG}$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['whole_path_frac_of_mfma_peak'], d['pipelined']['value'], (d.get('roofline_f32') or {}).get('value'))"
+  python3 -c "import json; d=json.loads(open('$O/bench_${TAG}$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['whole_path_frac_of_mfma_peak'], d['pipelined']['value'], (d['roofline'].get('reference_arithmetic') or {}).get('value'))"
 done
 cd /tmp
 rm -rf "$O"/prof_*
