@@ -17,7 +17,7 @@ namespace {
 
 void free_slot(Slot& s) {
     for (auto p : s.d_act) if (p) (void)hipFree(p);
-    void* misc[] = {s.d_partial, s.d_tab, s.d_packed, s.d_pose_partial};
+    void* misc[] = {s.d_partial, s.d_tab, s.d_packed, s.d_pose_partial, s.d_counters};
     for (auto p : misc) if (p) (void)hipFree(p);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     s = Slot();
@@ -34,6 +34,8 @@ int alloc_slot(davo_ctx* c, Slot* s) {
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_tab), (size_t)c->max_batch * 3 * NCLS * sizeof(float)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_pose_partial), NB * 2 * PH_SPLIT * 3 * sizeof(float)));
     HIP_TRY(c, hipMemset(s->d_partial, 0, (size_t)c->max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_counters), ((size_t)c->max_batch + 1) * sizeof(unsigned)));
+    HIP_TRY(c, hipMemset(s->d_counters, 0, ((size_t)c->max_batch + 1) * sizeof(unsigned)));
     return DAVO_OK;
 }
 
@@ -559,6 +561,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "merge_rem") c->opt_merge_rem = value != 0;
     else if (k == "patch_cnv2") c->opt_patch_cnv2 = value != 0;
     else if (k == "patch_cnv3") c->opt_patch_cnv3 = value != 0;
+    else if (k == "fold_tails") c->opt_fold_tails = value != 0;
     else if (k == "auto_range") { int rc = judge_pending(c); if (rc) return rc; c->opt_auto_range = value != 0; }
     else if (k == "force_tile") {
         // test hook: every f16x3 layer the tile fits runs as ONE launch of that tile shape (plan.h tile ids; -1 = planner)

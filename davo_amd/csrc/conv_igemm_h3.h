@@ -35,6 +35,7 @@
 #include <stdint.h>
 
 #include "conv_igemm.h"
+#include "pose_tail.h"
 
 // measurement-only switches of the kernels (ConvParamsH::dbg) exist in a -DDAVO_TUNING build only; the product
 // library compiles them out
@@ -706,7 +707,10 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
             float t = 0.f;
             for (int w = 0; w < WM * WN; ++w) t += red[w * 6 + tid];
             p.pose_partial[(((long)grp * p.pose_mt + (mtile - p.mtile0)) * p.ntiles_n + ntile) * 6 + tid] = t;
+            if (p.pose_counter) __threadfence();
         }
+        // the workgroup that finishes last adds the tiles in fixed order and writes the poses (pose_tail.h)
+        if (p.pose_counter && last_workgroup(p.pose_counter, (unsigned)p.pose_total, reinterpret_cast<unsigned*>(red + 64))) pose_from_tiles_tail<WM * WN * 64>(p);
         return;
     }
 

@@ -330,7 +330,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
             float t = 0.f;
             for (int w = 0; w < T::WAVES; ++w) t += red[w * 6 + tid];
             p.pose_partial[(((long)grp * p.pose_mt + (mtile - p.mtile0)) * p.ntiles_n + ntile) * 6 + tid] = t;
+            if (p.pose_counter) __threadfence();
         }
+        // the workgroup that finishes last adds the tiles in fixed order and writes the poses (pose_tail.h)
+        if (p.pose_counter && last_workgroup(p.pose_counter, (unsigned)p.pose_total, reinterpret_cast<unsigned*>(red + 64))) pose_from_tiles_tail<T::THREADS>(p);
         return;
     }
 

@@ -63,6 +63,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     float *d_partial = nullptr, *d_tab = nullptr, *d_packed = nullptr, *d_pose_partial = nullptr;
     float* d_act[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned* d_counters = nullptr;              // "last workgroup" tickets (pose_tail.h): [0] cnv7's pose tail, [1 + b] triplet b's squeeze
 };
 
 // A batch davo_forward_device has issued and no verdict on its f16x3 range record has covered yet
@@ -90,6 +91,7 @@ struct davo_ctx {
     bool opt_patch_cnv2 = true;                // f16x3: cnv2 from an LDS-staged input patch (conv_patch_cnv2_h3) instead of the implicit GEMM
     bool opt_patch_cnv3 = true;                // f16x3: cnv3 likewise (conv_patch_cnv3_h3)
     bool opt_merge_rem = true;                 // f16x3: cnv5 / cnv6 main + remainder launches as one grid (conv_igemm_h3_mainrem)
+    bool opt_fold_tails = true;                // the excitation MLP and the pose head's tile sum run in the last workgroup of the squeeze / cnv7 launch
     bool opt_share_taps = true;                // f16x3: cnv3..cnv6 stage one pixel patch per filter row for its three taps
     float* d_pose_tiles = nullptr;             // per-tile partial sums of the fused pose head
     size_t pose_tiles_floats = 0;
@@ -113,6 +115,7 @@ struct davo_ctx {
     int H1, W1, H2, W2, H3, W3;
     // workspace
     float *d_partial = nullptr, *d_tab = nullptr, *d_packed = nullptr, *d_zeros = nullptr, *d_pose_partial = nullptr;
+    unsigned* d_counters = nullptr;            // the active slot's ticket counters
     float* d_act[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t act_floats_per_img[7];
     int act_ch[7];

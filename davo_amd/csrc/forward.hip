@@ -83,6 +83,7 @@ void activate_slot(davo_ctx* c, int i) {
     const Slot& s = c->slots[i];
     if (!(c->user_stream && i == 0)) c->stream = s.stream;
     c->d_partial = s.d_partial; c->d_tab = s.d_tab; c->d_packed = s.d_packed; c->d_pose_partial = s.d_pose_partial;
+    c->d_counters = s.d_counters;
     for (int k = 0; k < 7; ++k) c->d_act[k] = s.d_act[k];
 }
 
@@ -142,7 +143,7 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
 // ---- one conv layer, f16x3 path: x and y are split-fp16 blocked tensors (y float32 when y_f32) -----
 int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int Win, void* y, int y_ld,
                       bool y_f32, int NB, bool fuse_pose = false, int* pose_bm = nullptr, int* pose_mt = nullptr,
-                      int* pose_ntn = nullptr) {
+                      int* pose_ntn = nullptr, float* pose_out = nullptr) {
     const ConvLayer& L = c->L[li];
     ConvParamsH p{};
     int Ho, Wo, pt, pl;
@@ -187,6 +188,10 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;      // the slot this batch runs in
         p.y_mode = 2; p.pose_w = c->d_wpred; p.pose_partial = c->d_pose_tiles + (size_t)slot_idx * c->pose_tiles_floats;
         p.pose_P = P; p.pose_mt = mt;
+        if (c->opt_fold_tails && pose_out) {      // the launch's last workgroup adds the tiles and writes the poses (pose_tail.h)
+            p.pose_counter = c->d_counters; p.pose_bias = c->d_bpred; p.pose_out = pose_out;
+            p.pose_NB = NB; p.pose_bm = ts.bm; p.pose_total = L.groups * mt * ntn;
+        }
         if (pose_bm) *pose_bm = ts.bm;
         if (pose_mt) *pose_mt = mt;
         if (pose_ntn) *pose_ntn = ntn;
@@ -331,11 +336,19 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         auto it = c->weights.find(n);
         return it == c->weights.end() ? nullptr : it->second.dev;
     };
-    if (v.att_source == 1) {
+    const bool fold_excite = v.att_source == 1 && c->opt_fold_tails;
+    if (fold_excite) {
+        // squeeze + excitation in one launch: the workgroup that delivers a triplet's last partial sum evaluates its tables
+        ProfScope ps(c, "se_squeeze_partial");
+        HIP_TRY(c, launch_se_squeeze_excite(static_cast<const float*>(d_flow), B, HW, v, c->d_partial, c->d_counters + 1,
+                                            wdev("pose_exp_net/se_flow/bottleneck_fc/kernel"), wdev("pose_exp_net/se_flow/bottleneck_fc/bias"),
+                                            wdev("pose_exp_net/se_flow/recover_fc/kernel"), wdev("pose_exp_net/se_flow/recover_fc/bias"),
+                                            wdev("pose_exp_net/pose_exp_net/seg_channel_weight/weight"), c->d_tab, s));
+    } else if (v.att_source == 1) {
         ProfScope ps(c, "se_squeeze_partial");
         HIP_TRY(c, launch_se_squeeze(static_cast<const float*>(d_flow), B, HW, v, c->d_partial, s));
     }
-    {
+    if (!fold_excite) {
         ProfScope ps(c, "se_excite");
         HIP_TRY(c, launch_se_excite(c->d_partial, B, HW, v,
                                     wdev("pose_exp_net/se_flow/bottleneck_fc/kernel"), wdev("pose_exp_net/se_flow/bottleneck_fc/bias"),
@@ -378,7 +391,8 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         if ((rc = run_conv_layer_h3(c, 4, a[3], 128, c->H2, c->W2, a[4], 256, false, NB))) return rc;
         if ((rc = run_conv_layer_h3(c, 5, a[4], 256, c->H2, c->W2, a[5], 2 * c6, false, NB))) return rc;
         pose_fused = c->opt_fuse_pose && c->H3 * c->W3 >= 128;
-        if ((rc = run_conv_layer_h3(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, true, NB, pose_fused, &pose_bm, &pose_mt, &pose_ntn))) return rc;
+        if ((rc = run_conv_layer_h3(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, true, NB, pose_fused, &pose_bm, &pose_mt, &pose_ntn,
+                                    static_cast<float*>(d_pose)))) return rc;
         c->cnv7_valid = !pose_fused;
         c->range_dirty = true;
     } else if (c->impl == 0) {
@@ -405,7 +419,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
             if ((rc = run_direct(c, "cnv7", a[5], NB, c->H2, c->W2, c6, 2 * c6, h * c6, hp + "cnv7/weights", hp + "cnv7/biases", 3, 256, 2, 1, a[6], 512, h * 256))) return rc;
         }
     }
-    {
+    if (!(pose_fused && c->opt_fold_tails)) {
         ProfScope ps(c, "pose_head");
         if (pose_fused) {
             const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;

@@ -35,6 +35,11 @@ hipError_t launch_h3_generic(int KS, int stride, int tile, const ConvParamsH& p,
 hipError_t launch_se_squeeze(const float* d_flow, int B, int HW, const Variant& v, float* d_partial, hipStream_t s);
 hipError_t launch_se_excite(const float* d_partial, int B, int HW, const Variant& v, const float* w1, const float* b1,
                             const float* w2, const float* b2, const float* wstatic, float* d_tab, hipStream_t s);
+// squeeze + excitation in one launch: the last workgroup of each triplet evaluates its tables (prologue.h, pose_tail.h);
+// d_counters: one zeroed unsigned per triplet, left at zero
+hipError_t launch_se_squeeze_excite(const float* d_flow, int B, int HW, const Variant& v, float* d_partial, unsigned* d_counters,
+                                    const float* w1, const float* b1, const float* w2, const float* b2, const float* wstatic,
+                                    float* d_tab, hipStream_t s);
 // ld: 16 = split-fp16 8-channel layout (f16x3), 8 = float32 8-channel, 10 = the reference's 10-channel layout
 hipError_t launch_mask_pack(int ld, const uint8_t* d_img, const float* d_flow, const float* d_seg, const float* d_tab,
                             const Variant& v, int B, int H, int W, float* d_packed, hipStream_t s);

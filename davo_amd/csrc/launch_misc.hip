@@ -35,6 +35,14 @@ hipError_t launch_se_excite(const float* d_partial, int B, int HW, const Variant
     return hipGetLastError();
 }
 
+hipError_t launch_se_squeeze_excite(const float* d_flow, int B, int HW, const Variant& v, float* d_partial, unsigned* d_counters,
+                                    const float* w1, const float* b1, const float* w2, const float* b2, const float* wstatic,
+                                    float* d_tab, hipStream_t s) {
+    hipLaunchKernelGGL(se_squeeze_excite, dim3(SQ_CHUNKS, 2, B), dim3(256), 0, s, d_flow, HW, v, d_partial, d_counters, w1, b1, w2, b2,
+                       wstatic, d_tab);
+    return hipGetLastError();
+}
+
 hipError_t launch_mask_pack(int ld, const uint8_t* d_img, const float* d_flow, const float* d_seg, const float* d_tab,
                             const Variant& v, int B, int H, int W, float* d_packed, hipStream_t s) {
     const long nthreads = (long)2 * B * H * (W / 4);

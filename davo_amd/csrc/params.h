@@ -82,6 +82,12 @@ struct ConvParamsH {
     const float* pose_w;    // [groups][256][3] pred kernels
     float* pose_partial;    // [groups][pose_mt][ntiles_n][2 image slots][3]
     int pose_P, pose_mt;    // output pixels per image (>= tile height), M tiles in the launch
+    // the tail of the pose head inside the same launch (pose_tail.h): the workgroup that finishes LAST adds the tiles'
+    // partial sums in a fixed order and writes the poses; null pose_counter = a separate pose_from_tiles launch does it
+    unsigned* pose_counter; // one counter per in-flight slot, zero between launches
+    const float* pose_bias; // [groups][3] pred biases
+    float* pose_out;        // [NB][6]
+    int pose_NB, pose_bm, pose_total;   // pair images, tile height, workgroups of the launch
     int dbg;                // measurement only (DAVO_DBG; results are wrong with any bit set): 1 DMA reads the zero line,
                             // 2 no matrix phase, 4 no wave-half stagger (32x32x16 form), 32 no epilogue, 64 stores fold onto 256 tiles
 };

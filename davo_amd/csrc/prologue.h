@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "params.h"
+#include "pose_tail.h"
 
 namespace davo {
 
@@ -57,21 +58,25 @@ __global__ __launch_bounds__(256) void se_squeeze_partial(const float* __restric
     }
 }
 
-// SE pass 2 + excitation: tab[b][frame][19] for frame = (tgt, src0, src1).
-// One 64-lane wave per (triplet, frame): lanes 0..31 fetch the squeeze partials (fixed butterfly: bitwise reproducible),
-// every lane evaluates the 8 bottleneck units, lane c < 19 the class c of the recovery layer — the three dependent
-// steps of the MLP cost three memory round trips instead of the ~200 a single lane needed.
-__global__ __launch_bounds__(64) void se_excite(const float* __restrict__ partial, int HW, Variant v,
-                                                const float* __restrict__ w1, const float* __restrict__ b1,
-                                                const float* __restrict__ w2, const float* __restrict__ b2,
-                                                const float* __restrict__ wstatic,
-                                                float* __restrict__ tab) {
-    const int b = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x;
+// One wave's share of the excitation: tab[b][frame][19] for frame = (tgt, src0, src1).
+// Lanes 0..31 fetch the squeeze partials (fixed butterfly: bitwise reproducible), every lane evaluates the 8 bottleneck
+// units, lane c < 19 the class c of the recovery layer — the three dependent steps of the MLP cost three memory round
+// trips instead of the ~200 a single lane needed.  AGENT: the partials were written by other workgroups of the SAME
+// launch (se_squeeze_excite's last workgroup): read them past the non-coherent caches.
+template <bool AGENT>
+__device__ __forceinline__ void se_excite_wave(const float* __restrict__ partial, int HW, const Variant& v, int b, int frame, int lane,
+                                               const float* __restrict__ w1, const float* __restrict__ b1,
+                                               const float* __restrict__ w2, const float* __restrict__ b2,
+                                               const float* __restrict__ wstatic, float* __restrict__ tab) {
     float* t = tab + ((size_t)b * 3 + frame) * NCLS;
     if (v.att_source == 1 && frame >= 1) {
         const float* pp = partial + ((size_t)b * 2 + (frame - 1)) * SQ_CHUNKS * 2;
         static_assert(SQ_CHUNKS == 32, "one partial pair per lane of the lower half-wave");
-        float sx = lane < SQ_CHUNKS ? pp[2 * lane] : 0.f, sy = lane < SQ_CHUNKS ? pp[2 * lane + 1] : 0.f;
+        float sx = 0.f, sy = 0.f;
+        if (lane < SQ_CHUNKS) {
+            sx = AGENT ? agent_load(pp + 2 * lane) : pp[2 * lane];
+            sy = AGENT ? agent_load(pp + 2 * lane + 1) : pp[2 * lane + 1];
+        }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
         const float inv = 1.0f / (float)HW;
@@ -92,6 +97,59 @@ __global__ __launch_bounds__(64) void se_excite(const float* __restrict__ partia
         if ((v.att_source == 2 && frame >= 1) || v.att_source == 3) t[lane] = 1.0f / (1.0f + expf(-wstatic[lane]));
         else t[lane] = 1.0f;                                   // davo.py:1408-1412 / 1385-1389
     }
+}
+
+// SE pass 2 + excitation as a launch of its own: one 64-lane wave per (triplet, frame).  Used by the variants without a
+// squeeze (static / no attention) and with davo_set_option "fold_tails" 0.
+__global__ __launch_bounds__(64) void se_excite(const float* __restrict__ partial, int HW, Variant v,
+                                                const float* __restrict__ w1, const float* __restrict__ b1,
+                                                const float* __restrict__ w2, const float* __restrict__ b2,
+                                                const float* __restrict__ wstatic,
+                                                float* __restrict__ tab) {
+    se_excite_wave<false>(partial, HW, v, blockIdx.x, blockIdx.y, threadIdx.x, w1, b1, w2, b2, wstatic, tab);
+}
+
+// Squeeze and excitation in ONE launch (attention_module.py:64-67 then :89-101): se_squeeze_partial's body, and the
+// workgroup that delivers the LAST of a triplet's 2 x SQ_CHUNKS partial sums evaluates that triplet's three tables
+// (pose_tail.h: ticket counter per triplet, agent-scope fences).  Same sums in the same order as the two launches.
+__global__ __launch_bounds__(256) void se_squeeze_excite(const float* __restrict__ flow, int HW, Variant v,
+                                                         float* __restrict__ partial, unsigned* __restrict__ counters,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         const float* __restrict__ wstatic, float* __restrict__ tab) {
+    const int chunk = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+    const float4* f = reinterpret_cast<const float4*>(flow + ((size_t)b * 4 + s) * HW * 2);
+    const int nvec = HW / 2;                                   // HW is a multiple of 16
+    const int per = (nvec + SQ_CHUNKS - 1) / SQ_CHUNKS;
+    const int beg = chunk * per, end = min(beg + per, nvec);
+    float sx = 0.f, sy = 0.f;
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        float4 q = f[i];
+        if (v.norm_flow) {
+            q.x = (q.x - 0.32140523f) / 15.384229f; q.y = (q.y - 0.32140523f) / 15.384229f;
+            q.z = (q.z - 0.32140523f) / 15.384229f; q.w = (q.w - 0.32140523f) / 15.384229f;
+        }
+        if (v.abs_mode & 1) { q.x = fabsf(q.x); q.z = fabsf(q.z); }
+        if (v.abs_mode & 2) { q.y = fabsf(q.y); q.w = fabsf(q.w); }
+        sx += q.x + q.z;
+        sy += q.y + q.w;
+    }
+    __shared__ float red[2][4];
+    __shared__ unsigned ticket;
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wid] = sx; red[1][wid] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = partial + (((size_t)b * 2 + s) * SQ_CHUNKS + chunk) * 2;
+        o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        __threadfence();
+    }
+    if (!last_workgroup(counters + b, 2u * SQ_CHUNKS, &ticket)) return;
+    if (wid < 3) se_excite_wave<true>(partial, HW, v, b, wid, lane, w1, b1, w2, b2, wstatic, tab);
+    if (threadIdx.x == 0) __hip_atomic_store(counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ float att_lookup(const float* tab19, float seg) {

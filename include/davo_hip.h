@@ -176,6 +176,10 @@ int davo_range_stats(davo_ctx* ctx, long long* recalibrations, long long* f32_ba
  * Kernel-fusion switches of the f16x3 path (both modes give the same poses to ~1e-7):
  *   "fuse_pose" (default 1): pred 1x1 + spatial mean + 0.01 (nets/posenn.py:240-250) run in cnv7's
  *       epilogue; the cnv7 activation is never written to HBM.  0 = cnv7 stored, separate pose-head kernels.
+ *   "fold_tails" (default 1): the 2->8->19 excitation MLP runs in the workgroup of the squeeze launch that delivers a
+ *       triplet's last partial sum, and the pose head's sum over cnv7's tiles in the workgroup of the cnv7 launch that
+ *       finishes last (csrc/pose_tail.h: ticket counters, agent-scope fences, fixed summation order): two launches fewer
+ *       per batch.  0 = se_excite / pose_from_tiles as launches of their own.  Bit-identical results.
  *   "fuse_pack" (default 0): cnv1 builds its input patch from the raw inputs (mask + pack fused in).
  *   "patch_cnv2", "patch_cnv3" (default 1): cnv2 (5x5 stride 2) / cnv3 (3x3 dilation 2) read their taps from an LDS-staged
  *       input patch (csrc/conv_patch_h3.h); 0 = the implicit-GEMM kernel.  The two sum a pixel's taps in different orders:

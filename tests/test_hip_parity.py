@@ -1087,3 +1087,31 @@ def test_bench_multi_gpu_code_path_on_one_gpu(tmp_path):
     assert res["timing"]["dominant_launch_ms"]["n"] == 3 and res["timing"]["step_ms_on_stream"]["n"] == 2
     assert res["max_abs_err_vs_oracle"] <= 1e-4 * res["max_abs_ref"]
     assert res["config"]["workload"].startswith("none of BASELINE.json's configs")
+
+
+@pytest.mark.parametrize("B,H,W", [(32, 128, 416), (5, 128, 416), (3, 64, 96), (1, 128, 416)])
+def test_folded_tails_are_bit_identical(B, H, W):
+    """"fold_tails": the excitation MLP in the squeeze launch's last workgroup (per triplet) and the pose head's tile sum in
+    the cnv7 launch's last workgroup give the bits of the separate se_excite / pose_from_tiles launches — whichever
+    workgroup happens to be last, launch after launch, and with two batches in flight."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(min(B, 4), H, W)
+    reps = -(-B // img.shape[0])
+    img, flow, seg = (np.concatenate([a] * reps)[:B] for a in (img, flow, seg))
+    e = _engine(cfg, H, W, B, synth.make_weights(cfg), "f16x3")
+    e.set_option("fold_tails", 0)
+    want = e.forward(img, flow, seg).copy()
+    tab = e.debug_read("att_table", (B, 3, 19)).copy()
+    e.set_option("fold_tails", 1)
+    for _ in range(3):
+        assert np.array_equal(e.forward(img, flow, seg), want)
+        assert np.array_equal(e.debug_read("att_table", (B, 3, 19)), tab)
+    e.set_inflight(2)
+    sets = [(e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48))
+            for _ in range(2)]
+    for i in range(8):
+        e.forward_device(B, *sets[i % 2])
+    e.synchronize()
+    for st in sets:
+        assert np.array_equal(st[3].download((B, 2, 6)), want)
+    e.close()
