@@ -603,9 +603,12 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
         } else {
         H3_DMA_CHUNK(0, 0)
         if constexpr (NST >= 3) {
+            static_assert(NST <= 6, "ring depth");
             if (p.nchunks >= NST - 1) {
                 H3_DMA_CHUNK(1, 1)
-                if constexpr (NST == 4) H3_DMA_CHUNK(2, 2)
+                if constexpr (NST >= 4) H3_DMA_CHUNK(2, 2)
+                if constexpr (NST >= 5) H3_DMA_CHUNK(3, 3)
+                if constexpr (NST >= 6) H3_DMA_CHUNK(4, 4)
             }
         }
         if (NST >= 3 && p.nchunks >= NST - 1) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
@@ -706,8 +709,9 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
         if (tid < 6) {
             float t = 0.f;
             for (int w = 0; w < WM * WN; ++w) t += red[w * 6 + tid];
-            p.pose_partial[(((long)grp * p.pose_mt + (mtile - p.mtile0)) * p.ntiles_n + ntile) * 6 + tid] = t;
-            if (p.pose_counter) __threadfence();
+            float* dst = p.pose_partial + (((long)grp * p.pose_mt + (mtile - p.mtile0)) * p.ntiles_n + ntile) * 6 + tid;
+            if (p.pose_counter) { agent_store(dst, t); agent_stores_done(); }      // read by the launch's last workgroup
+            else *dst = t;
         }
         // the workgroup that finishes last adds the tiles in fixed order and writes the poses (pose_tail.h)
         if (p.pose_counter && last_workgroup(p.pose_counter, (unsigned)p.pose_total, reinterpret_cast<unsigned*>(red + 64))) pose_from_tiles_tail<WM * WN * 64>(p);

@@ -329,8 +329,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
         if (tid < 6) {
             float t = 0.f;
             for (int w = 0; w < T::WAVES; ++w) t += red[w * 6 + tid];
-            p.pose_partial[(((long)grp * p.pose_mt + (mtile - p.mtile0)) * p.ntiles_n + ntile) * 6 + tid] = t;
-            if (p.pose_counter) __threadfence();
+            float* dst = p.pose_partial + (((long)grp * p.pose_mt + (mtile - p.mtile0)) * p.ntiles_n + ntile) * 6 + tid;
+            if (p.pose_counter) { agent_store(dst, t); agent_stores_done(); }      // read by the launch's last workgroup
+            else *dst = t;
         }
         // the workgroup that finishes last adds the tiles in fixed order and writes the poses (pose_tail.h)
         if (p.pose_counter && last_workgroup(p.pose_counter, (unsigned)p.pose_total, reinterpret_cast<unsigned*>(red + 64))) pose_from_tiles_tail<T::THREADS>(p);

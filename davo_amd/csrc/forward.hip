@@ -223,6 +223,7 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         p.M = plan[i].row0 + plan[i].rows;                    // rows past this launch's range are not its job
         const int mtiles = (plan[i].rows + ts.bm - 1) / ts.bm;
         dim3 grid(mtiles * p.ntiles_n, L.groups);
+        p.deep = c->opt_deep_ring && plan.size() == 1 && (long)grid.x * grid.y <= c->ncu;       // at most one workgroup per CU
         c->last_plan[li][i] = ((plan[i].rows + 127) / 128) * 1000 + plan[i].tile;
         const std::string label = i == 0 ? std::string(L.label) : std::string(L.label) + ".rem";
         {

@@ -74,9 +74,40 @@ hipError_t launch_c(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     return launch_m<KS, STRIDE, WM, WN, TM, TN, LAYER, SMALLC, false>(p, grid, s);
 }
 
+// Deep rings.  A launch of at most one workgroup per CU (batch 1..4: cnv6 at B = 1 is 104 tiles of 128x128 on 256 CUs) has
+// no second workgroup to hide the LDS-DMA latency behind, and with two ring slots only one chunk is in flight: a chunk then
+// costs a memory round trip (0.7 us on cnv6, 1.3 us on cnv7's stride-2 gather, against 0.1-0.3 us of matrix work).  Such
+// launches take as many ring slots as the LDS holds: the wait is counted (vmcnt), so NSTG - 1 chunks stay in flight.
+// Same tiles, same products in the same order: bit-identical to the two-slot kernels.
+template <int KS, int STRIDE, int LAYER, int MAXBN>
+hipError_t launch_tile_deep(int tile, const ConvParamsH& p, dim3 grid, hipStream_t s, bool* handled) {
+    *handled = true;
+    if (tile == TILE_128x32) return launch_m<KS, STRIDE, 4, 1, 1, 1, LAYER, false, true, 6>(p, grid, s);           // 6 x 20 KB
+    if constexpr (MAXBN >= 64)
+        if (tile == TILE_256x64) return launch_m<KS, STRIDE, 4, 2, 2, 1, LAYER, false, true, 3>(p, grid, s);       // 3 x 40 KB
+    if constexpr (MAXBN >= 128) {
+        if (tile == TILE_128x128) {
+            if constexpr (LAYER == 7) return launch_m<KS, STRIDE, 2, 2, 2, 2, LAYER, false, true, 4>(p, grid, s);  // 4 x 32 KB
+            else return launch_m<KS, STRIDE, 4, 2, 1, 2, LAYER, false, true, 4>(p, grid, s);
+        }
+        if (tile == TILE_256x128) return launch_m<KS, STRIDE, 4, 2, 2, 2, LAYER, false, true, 3>(p, grid, s);      // 3 x 48 KB
+    }
+    if constexpr (MAXBN >= 256)
+        if (tile == TILE_128x256) return launch_m<KS, STRIDE, 2, 4, 2, 2, LAYER, false, true, 3>(p, grid, s);
+    *handled = false;
+    return hipSuccess;
+}
+
 // MAXBN bounds the instantiations to the N tiles a layer can use (its padded Cout)
 template <int KS, int STRIDE, int LAYER, bool SMALLC, int MAXBN>
 hipError_t launch_tile(int tile, const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    if constexpr (LAYER >= 4 && !SMALLC) {
+        if (p.deep && use_m16()) {
+            bool handled = false;
+            const hipError_t e = launch_tile_deep<KS, STRIDE, LAYER, MAXBN>(tile, p, grid, s, &handled);
+            if (handled) return e;
+        }
+    }
     if (tile == TILE_128x32) return launch_c<KS, STRIDE, 4, 1, 1, 1, LAYER, SMALLC>(p, grid, s);
     if constexpr (MAXBN >= 64)
         if (tile == TILE_256x64) return launch_c<KS, STRIDE, 4, 2, 2, 1, LAYER, SMALLC>(p, grid, s);

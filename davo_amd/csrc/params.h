@@ -72,6 +72,7 @@ struct ConvParamsH {
     int Mtot;               // output rows of the whole layer (M is this launch's upper row bound): shared-tap staging reads the
                             // pixels RATE before and after a tile, which may belong to the layer's other launch
     int xs;                 // host: issue the shared-tap instantiation (conv_igemm_h3 RATE > 0) where the layer has one
+    int deep;               // host: the launch has at most one workgroup per CU - issue the deep-ring instantiation of its tile
     int g_x_boff, g_y_coff;
     long g_w, g_bias;
     float out_scale;        // 2^(shift_out - shift_in) / (power of two the layer's weights were multiplied by)

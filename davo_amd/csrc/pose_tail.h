@@ -1,11 +1,15 @@
 // pose_tail.h — "last workgroup" tails: the final, tiny reduction of a launch done by whichever workgroup of that
 // launch finishes last, instead of by a launch of its own (a 5-7 us launch for a few hundred additions).
 //
-// Protocol (the classic threadfence reduction): a workgroup writes its partial results, each writing thread fences
-// (release at agent scope: the XCDs' L2s are separate), the workgroup synchronises, one thread takes a ticket from an
-// agent-scope atomic counter.  The holder of the last ticket fences again (acquire) and reads every workgroup's
-// partials with agent-scope loads, in a FIXED order - the sums are bitwise the same as the separate kernel's and do
-// not depend on which workgroup happens to be last.  It leaves the counter at zero for the next launch on the stream.
+// Protocol.  MI355X has one L2 per XCD and they are not coherent with each other, so the textbook form (plain stores,
+// __threadfence(), atomic ticket) costs a release fence = a write-back of the XCD's whole L2 (buffer_wbl2) per workgroup:
+// measured +70 us on the squeeze launch and +19 us on cnv7.  Instead the few words that cross workgroups are moved with
+// AGENT-SCOPE accesses, which go through to the memory side on their own: the partial results are written with agent-scope
+// atomic stores, the writing wave waits for their acknowledgement (s_waitcnt vmcnt(0): gfx950 counts stores there), the
+// workgroup synchronises, and one thread takes a ticket from an agent-scope atomic counter.  The holder of the last ticket
+// reads every workgroup's partials with agent-scope loads, in a FIXED order - the sums are bitwise the same as the separate
+// kernel's and do not depend on which workgroup happens to be last.  It leaves the counter at zero for the next launch on
+// the stream.  No fence, no cache write-back.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,17 +20,24 @@ namespace davo {
 __device__ __forceinline__ float agent_load(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void agent_store(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the calling wave's agent-scope stores have been acknowledged (vmcnt(0); expcnt / lgkmcnt untouched)
+__device__ __forceinline__ void agent_stores_done() {
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+    asm volatile("" ::: "memory");
+}
 
-// Every thread of the workgroup calls this after the partial results were written and fenced by their writers.
+// Every thread of the workgroup calls this after the partial results were written with agent_store and their writers
+// passed agent_stores_done().
 // ticket_lds: one free word of the workgroup's LDS (the kernels' LDS budgets are exact, so no static __shared__ here).
 // -> true in every thread of the one workgroup that took the last of `total` tickets.
 __device__ __forceinline__ bool last_workgroup(unsigned* counter, unsigned total, unsigned* ticket_lds) {
     __syncthreads();
-    if (threadIdx.x == 0) *ticket_lds = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) *ticket_lds = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    const bool last = *ticket_lds == total - 1;
-    if (last) __threadfence();
-    return last;
+    return *ticket_lds == total - 1;
 }
 
 // pose[n][head*3+k] = 0.01 * (bias + (1/P) * sum over the tiles that cover image n); same order as pose_from_tiles

@@ -143,9 +143,9 @@ __global__ __launch_bounds__(256) void se_squeeze_excite(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         float* o = partial + (((size_t)b * 2 + s) * SQ_CHUNKS + chunk) * 2;
-        o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        __threadfence();
+        agent_store(o, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        agent_store(o + 1, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+        agent_stores_done();
     }
     if (!last_workgroup(counters + b, 2u * SQ_CHUNKS, &ticket)) return;
     if (wid < 3) se_excite_wave<true>(partial, HW, v, b, wid, lane, w1, b1, w2, b2, wstatic, tab);

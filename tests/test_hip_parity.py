@@ -1099,19 +1099,49 @@ def test_folded_tails_are_bit_identical(B, H, W):
     reps = -(-B // img.shape[0])
     img, flow, seg = (np.concatenate([a] * reps)[:B] for a in (img, flow, seg))
     e = _engine(cfg, H, W, B, synth.make_weights(cfg), "f16x3")
-    e.set_option("fold_tails", 0)
-    want = e.forward(img, flow, seg).copy()
-    tab = e.debug_read("att_table", (B, 3, 19)).copy()
-    e.set_option("fold_tails", 1)
-    for _ in range(3):
-        assert np.array_equal(e.forward(img, flow, seg), want)
-        assert np.array_equal(e.debug_read("att_table", (B, 3, 19)), tab)
-    e.set_inflight(2)
     sets = [(e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48))
             for _ in range(2)]
+    e.set_option("fold_tails", 0)
+    e.forward_device(B, *sets[0])
+    e.synchronize()
+    want = sets[0][3].download((B, 2, 6))
+    tab = e.debug_read("att_table", (B, 3, 19)).copy()
+    assert np.isfinite(want).all() and np.abs(want).max() > 1e-3
+    e.set_option("fold_tails", 1)
+    for _ in range(3):
+        sets[0][3].upload(np.zeros((B, 2, 6), np.float32))
+        e.forward_device(B, *sets[0])
+        e.synchronize()
+        assert np.array_equal(sets[0][3].download((B, 2, 6)), want)
+        assert np.array_equal(e.debug_read("att_table", (B, 3, 19)), tab)
+    e.set_inflight(2)
     for i in range(8):
         e.forward_device(B, *sets[i % 2])
     e.synchronize()
     for st in sets:
         assert np.array_equal(st[3].download((B, 2, 6)), want)
+    e.close()
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 128, 416), (2, 128, 416), (4, 128, 416), (1, 64, 96), (3, 36, 100), (1, 256, 832)])
+def test_deep_ring_is_bit_identical(c_oracle, B, H, W):
+    """"deep_ring": launches of at most one workgroup per CU (small batches) run the same tiles on LDS rings of 3..6 slots
+    instead of 2 (more chunks of LDS-DMA in flight): same products in the same order, so every activation and pose is
+    bit-identical — also with every tile shape forced in turn."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(B, H, W)
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, H, W, B, weights, "f16x3")
+    for tile in (-1, 0, 1, 2, 3, 4):
+        e.set_option("force_tile", tile)
+        e.set_option("deep_ring", 0)
+        want = e.forward(img, flow, seg).copy()
+        acts = {k: e.debug_read(k, (2 * B, (H + 3) // 4, (W + 3) // 4, ch)).copy() for k, ch in (("cnv4", 128), ("cnv5", 256), ("cnv6", 256))}
+        e.set_option("deep_ring", 1)
+        got = e.forward(img, flow, seg)
+        assert np.array_equal(got, want), ("tile", tile)
+        for k, ch in (("cnv4", 128), ("cnv5", 256), ("cnv6", 256)):
+            assert np.array_equal(e.debug_read(k, (2 * B, (H + 3) // 4, (W + 3) // 4, ch)), acts[k]), (k, "tile", tile)
+    if H * W <= 128 * 416:
+        assert_pose_close(got, c_oracle.forward(cfg, img, flow, seg, weights), "deep ring %dx%d B=%d" % (H, W, B))
     e.close()

@@ -81,6 +81,9 @@ def main():
     print("B=%d %dx%d; ms per launch, median over %d rounds; columns = %s %s" % (B, H, W, a.rounds, "options" if a.arms else "force_tile", tiles))
     for k in names:
         print("%-20s" % k + "".join("%10.4f" % (np.median(acc[t][k]) if k in acc[t] else float("nan")) for t in tiles))
+    names_t = {0: "128x32", 1: "256x64", 2: "256x128", 3: "128x256", 4: "128x128", 5: "256x256", 6: "208x256", 7: "256x256+128x128 merged"}
+    print("last arm's launch plans (mtiles of 128 rows x tile): " + "; ".join(
+        "cnv%d %s" % (li + 1, [(m, names_t.get(t, t)) for m, t in e.last_plan(li)]) for li in range(3, 7)))
     print("%-20s" % "step (wall, no events)" + "".join("%10.4f" % np.median(wall[t]) for t in tiles))
     print("%-20s" % "triplets/s" + "".join("%10.0f" % (B / np.median(wall[t]) * 1e3) for t in tiles))
 
