@@ -13,6 +13,16 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 UNITS = ("api", "forward", "plan", "weights", "launch_f32", "launch_h3", "launch_h3s", "launch_h3_generic", "launch_misc", "comm")
 
 
+# -fno-slp-vectorize: with SLP vectorisation hipcc (ROCm 7.2) fuses neighbouring scalar float updates into packed
+# v_pk_fma_f32 / v_pk_mul_f32 with op_sel operand swizzles.  In the fused pose-head epilogue of cnv7 (128x32 tiles, tiles that
+# straddle two images) one lane-sum of such a sequence came out different from launch to launch once three or more waves
+# shared a SIMD (batch >= 3 with that tile): poses off by up to 4e-3, one forward in three (tools/exp/flake_count.py;
+# round-2 library included).  With asm barriers between the six updates - or without SLP vectorisation anywhere - 0 of 300
+# forwards differ and the step time is level (26.35 k vs 26.35 k triplets/s at B = 32), so no device code of this library
+# contains packed-float32 arithmetic (tools/check_isa.py fails the build if one appears).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"]
+
+
 def lib_path(suffix=None):
     """DAVO_LIB_SUFFIX (or `suffix`) selects an experimental build made by tools/build_variant.py, e.g. the
     `_tuning` library with the measurement knobs compiled in; unset = the product library."""
@@ -53,7 +63,7 @@ def build(force=False, verbose=False, suffix=None, extra_flags=()):
         return out
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+    flags = HIPCC_FLAGS + ["-fPIC", "-Wall", "-Wno-unused-function"] + \
         list(extra_flags) + os.environ.get("DAVO_EXTRA_HIPCC_FLAGS", "").split()
     objdir = os.path.join(CSRC, "build%s" % (suffix if suffix is not None else os.environ.get("DAVO_LIB_SUFFIX", "")))
     os.makedirs(objdir, exist_ok=True)

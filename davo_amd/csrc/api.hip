@@ -616,6 +616,11 @@ int davo_debug_read(davo_ctx* c, const char* tensor, float* host_out, size_t n_f
         for (int i = 0; i < 7; ++i)
             if (t == names[i]) { src = c->d_act[i]; n = NB * c->act_floats_per_img[i]; }
     }
+    if (t == "pose_tiles") {          // the fused pose head's per-tile partial sums of the last batch (slot 0's region)
+        if (c->cnv7_valid || !c->d_pose_tiles) return fail(c, DAVO_ERR_NOT_READY, "the pose head did not run fused");
+        if (n_floats > c->pose_tiles_floats) return fail(c, DAVO_ERR_INVALID, "pose_tiles holds %zu floats", c->pose_tiles_floats);
+        return davo_memcpy_d2h(c, host_out, c->d_pose_tiles, n_floats * sizeof(float));
+    }
     if (t == "cnv7" && !c->cnv7_valid)
         return fail(c, DAVO_ERR_NOT_READY, "cnv7 was not materialised: the pose head ran fused (davo_set_option(ctx, \"fuse_pose\", 0))");
     if (!src) return fail(c, DAVO_ERR_INVALID, "unknown tensor `%s'", tensor);

@@ -78,18 +78,17 @@ __device__ __forceinline__ const uint8_t* patch_src(bool ok, const uint8_t* img,
 
 // Two activations -> their stored form: v = min(max(x * scale, 0), 65504) (ReLU; 65504 = the fp16 range),
 // H = {fp16(v0), fp16(v1)}, L = {fp16(v0 - H0), fp16(v1 - H1)}; vm collects max v before the upper clamp (range monitor).
-// On 2-vectors so that hipcc emits the packed forms (v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32): same roundings.
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Scalar float arithmetic on purpose: no device code of this library uses packed float32 instructions (v_pk_mul_f32 /
+// v_pk_add_f32 / v_pk_fma_f32; davo_amd/_lib.py, HIPCC_FLAGS).  Same roundings as the 2-vector form it replaces.
 __device__ __forceinline__ void split_pair_relu(float x0, float x1, float scale, float& vm, unsigned& H, unsigned& L) {
-    f32x2 v = f32x2{x0, x1} * scale;
-    v = __builtin_elementwise_max(v, f32x2{0.f, 0.f});
-    vm = fmaxf(vm, fmaxf(v[0], v[1]));
-    v = __builtin_elementwise_min(v, f32x2{65504.f, 65504.f});
-    const half2v hi = __builtin_convertvector(v, half2v);
-    const half2v lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), half2v);
-    H = __builtin_bit_cast(unsigned, hi);
-    L = __builtin_bit_cast(unsigned, lo);
+    float v0 = fmaxf(x0 * scale, 0.f), v1 = fmaxf(x1 * scale, 0.f);
+    vm = fmaxf(vm, fmaxf(v0, v1));
+    v0 = fminf(v0, 65504.f);
+    v1 = fminf(v1, 65504.f);
+    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+    const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+    H = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    L = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
 }
 
 // Persistent form: the grid is 3 workgroups per CU; each loads the 28 KB of B fragments into registers

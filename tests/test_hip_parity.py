@@ -1145,3 +1145,28 @@ def test_deep_ring_is_bit_identical(c_oracle, B, H, W):
     if H * W <= 128 * 416:
         assert_pose_close(got, c_oracle.forward(cfg, img, flow, seg, weights), "deep ring %dx%d B=%d" % (H, W, B))
     e.close()
+
+
+@pytest.mark.parametrize("B,tile", [(4, 0), (8, 0), (3, -1), (1, -1), (5, 4)])
+def test_pose_is_identical_launch_after_launch(B, tile):
+    """Regression: with 128x32 tiles on cnv7 (what the planner picks at batch 1) and three or more workgroups per CU
+    (batch >= 3), the fused pose head's sums over tiles that straddle two images differed from launch to launch —
+    compiler-formed packed float32 FMAs (v_pk_fma_f32 with op_sel) in the epilogue, one forward in three off by up to
+    4e-3 (davo_amd/_lib.py, HIPCC_FLAGS; tools/exp/flake_count.py).  Two hundred forwards of one batch must agree to the bit."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    H, W = 128, 416
+    img, flow, seg = synth.make_inputs(B, H, W)
+    e = _engine(cfg, H, W, B, synth.make_weights(cfg), "f16x3")
+    e.set_option("force_tile", tile)
+    bufs = (e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48))
+    ref, bad = None, 0
+    for _ in range(200):
+        e.forward_device(B, *bufs)
+        e.synchronize()
+        pose = bufs[3].download((B, 2, 6))
+        if ref is None:
+            ref = pose
+        elif not np.array_equal(pose, ref):
+            bad += 1
+    assert bad == 0, "%d of 199 forwards differ from the first" % bad
+    e.close()

@@ -16,9 +16,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FORBIDDEN = re.compile(r"^\s*(s_load_|s_buffer_load|s_scratch_load|ds_bpermute|ds_permute|ds_swizzle|ds_write|ds_add|ds_read_(?!b128)|s_sendmsg|s_memtime|s_memrealtime|flat_)")
 
 
+sys.path.insert(0, ROOT)
+from davo_amd._lib import HIPCC_FLAGS                                # noqa: E402  (the library's own device-code flags)
+
+PACKED_F32 = re.compile(r"^\s*(v_pk_(fma|mul|add)_f32)\b")
+
+
 def compile_to_asm(out, unit="launch_h3.hip"):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-S", "--cuda-device-only",
                            "-o", out, os.path.join(ROOT, "davo_amd", "csrc", unit)], stderr=subprocess.DEVNULL)
+
+
+def check_no_packed_f32(path):
+    """davo_amd/_lib.py, HIPCC_FLAGS: packed float32 arithmetic (compiler-formed v_pk_fma_f32 with op_sel) gave launch-to-launch
+    different sums on gfx950; the library is built without SLP vectorisation and must not contain any."""
+    hits = {}
+    kernel = None
+    for line in open(path):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kernel = m.group(1)
+        m = PACKED_F32.match(line)
+        if m:
+            hits[kernel] = hits.get(kernel, 0) + 1
+    return ["%s: %d packed float32 instruction(s)" % (k, n) for k, n in sorted(hits.items(), key=lambda kv: str(kv[0]))]
 
 
 def check_patch_loops(path):
@@ -122,12 +143,18 @@ def main():
         nk, nc, problems = check(sys.argv[1], kinds)
     else:
         nk, nc, problems = 0, 0, []
+        from concurrent.futures import ThreadPoolExecutor
         with tempfile.TemporaryDirectory() as d:
+            units = ("launch_h3.hip", "launch_h3s.hip", "launch_misc.hip", "launch_f32.hip", "launch_h3_generic.hip")
+            outs = {u: os.path.join(d, u.replace(".hip", ".s")) for u in units}
+            with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 2)) as ex:
+                list(ex.map(lambda u: compile_to_asm(outs[u], u), units))
             for unit in ("launch_h3.hip", "launch_h3s.hip"):          # the merged grid lives in launch_h3.hip, the 208x256 tile in its own unit
-                out = os.path.join(d, unit.replace(".hip", ".s"))
-                compile_to_asm(out, unit)
-                k, c, pr = check(out, kinds)
+                k, c, pr = check(outs[unit], kinds)
                 nk, nc, problems = nk + k, nc + c, problems + pr
+            for unit in units:
+                problems += ["%s: %s" % (unit, p) for p in check_no_packed_f32(outs[unit])]
+            npk, pprob = check_patch_loops(outs["launch_misc.hip"])
         for kind in KINDS:                                            # a family the name pattern no longer matches is a hole, not a pass
             if not kinds.get(kind):
                 problems.append("no %s kernel found: the guard does not see that kernel family" % kind)
@@ -135,12 +162,9 @@ def main():
           (nk, ", ".join("%s: %d" % (k, kinds.get(k, 0)) for k in KINDS), nc, len(problems)))
     for p in problems[:20]:
         print("  " + p)
-    npk, pprob = 1, []
-    if len(sys.argv) <= 1:
-        with tempfile.TemporaryDirectory() as d:
-            out = os.path.join(d, "launch_misc.s")
-            compile_to_asm(out, "launch_misc.hip")
-            npk, pprob = check_patch_loops(out)
+    if len(sys.argv) > 1:
+        npk, pprob = 1, []
+    else:
         print("%d patch kernels checked, %d problem(s)" % (npk, len(pprob)))
         for p in pprob[:20]:
             print("  " + p)
