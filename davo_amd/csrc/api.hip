@@ -556,12 +556,12 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     if (!c || !key) return DAVO_ERR_INVALID;
     const std::string k = key;
     if (k == "fuse_pose") c->opt_fuse_pose = value != 0;
-    else if (k == "fuse_pack") c->opt_fuse_pack = value != 0;
+    else if (k == "fuse_pack") c->opt_fuse_pack = value < 0 ? -1 : (value != 0);
     else if (k == "share_taps") c->opt_share_taps = value != 0;
     else if (k == "merge_rem") c->opt_merge_rem = value != 0;
     else if (k == "patch_cnv2") c->opt_patch_cnv2 = value != 0;
     else if (k == "patch_cnv3") c->opt_patch_cnv3 = value != 0;
-    else if (k == "fold_tails") c->opt_fold_tails = value != 0;
+    else if (k == "fold_tails") c->opt_fold_tails = value < 0 ? -1 : (value > 2 ? 1 : value);
     else if (k == "deep_ring") c->opt_deep_ring = value != 0;
     else if (k == "auto_range") { int rc = judge_pending(c); if (rc) return rc; c->opt_auto_range = value != 0; }
     else if (k == "force_tile") {

@@ -425,7 +425,11 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
         else if constexpr ((s_) - TX::APC == 3) { H3_DMA_B(3) }                                    \
     }
 #define H3_XSLOTS_OF_GROUP(g_, KX_, nabuf_)                                                                     \
-    { H3_XSLOT((g_) * DPGX, KX_, nabuf_) H3_XSLOT((g_) * DPGX + 1, KX_, nabuf_) H3_XSLOT((g_) * DPGX + 2, KX_, nabuf_) }
+    {                                                                                                           \
+        H3_XSLOT((g_) * DPGX, KX_, nabuf_)                                                                      \
+        if constexpr (DPGX >= 2) H3_XSLOT((g_) * DPGX + 1, KX_, nabuf_)                                         \
+        if constexpr (DPGX >= 3) H3_XSLOT((g_) * DPGX + 2, KX_, nabuf_)                                         \
+    }
 #define H3_GROUPX(J_, KX_, nabuf_)                                                                              \
     if constexpr ((J_) < NJ) {                                                                     \
         if constexpr ((J_) + 2 < NJ) {                                                             \

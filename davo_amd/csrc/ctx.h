@@ -87,11 +87,11 @@ struct davo_ctx {
     bool cu_partition = false;                 // davo_set_option "cu_partition": slot i's stream is masked to its own share of every XCD's CUs
     bool user_stream = false;
     bool opt_fuse_pose = true;                 // f16x3: pose head fused into cnv7's epilogue (davo_set_option)
-    bool opt_fuse_pack = false;                // f16x3: mask+pack fused into cnv1's patch fill
+    int opt_fuse_pack = -1;                    // f16x3: mask+pack fused into cnv1's patch fill: 0 off | 1 on | -1 where it pays (small batches: one launch fewer)
     bool opt_patch_cnv2 = true;                // f16x3: cnv2 from an LDS-staged input patch (conv_patch_cnv2_h3) instead of the implicit GEMM
     bool opt_patch_cnv3 = true;                // f16x3: cnv3 likewise (conv_patch_cnv3_h3)
     bool opt_merge_rem = true;                 // f16x3: cnv5 / cnv6 main + remainder launches as one grid (conv_igemm_h3_mainrem)
-    bool opt_fold_tails = false;               // the excitation MLP and the pose head's tile sum run in the last workgroup of the squeeze / cnv7 launch
+    int opt_fold_tails = -1;                   // 0 off | 1 both tails | 2 the excitation only | -1 auto: the excitation at small batches (pose_tail.h: what it costs)               // the excitation MLP and the pose head's tile sum run in the last workgroup of the squeeze / cnv7 launch
     bool opt_deep_ring = true;                 // f16x3: launches of at most one workgroup per CU (batch 1..4) run on LDS rings of 3..6 slots
     bool opt_share_taps = true;                // f16x3: cnv3..cnv6 stage one pixel patch per filter row for its three taps
     float* d_pose_tiles = nullptr;             // per-tile partial sums of the fused pose head

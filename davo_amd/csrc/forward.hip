@@ -108,6 +108,9 @@ int check_range(davo_ctx* c, const unsigned raw[6]) {
 
 namespace {
 
+constexpr int FOLD_EXCITE_MAX_BATCH = 2;       // auto modes: largest batch that folds the excitation / fuses mask + pack into cnv1
+constexpr int FUSE_PACK_MAX_BATCH = 0;        // measured level at every batch (cnv1 +5 us for mask_pack's 6.7): nowhere by default
+
 // ---- one conv layer, FP32-MFMA path ---------------------------------------------------------------
 int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int Win, float* y, int y_ld, int NB) {
     const ConvLayer& L = c->L[li];
@@ -188,7 +191,7 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;      // the slot this batch runs in
         p.y_mode = 2; p.pose_w = c->d_wpred; p.pose_partial = c->d_pose_tiles + (size_t)slot_idx * c->pose_tiles_floats;
         p.pose_P = P; p.pose_mt = mt;
-        if (c->opt_fold_tails && pose_out) {      // the launch's last workgroup adds the tiles and writes the poses (pose_tail.h)
+        if (pose_out) {      // the launch's last workgroup adds the tiles and writes the poses (pose_tail.h)
             p.pose_counter = c->d_counters; p.pose_bias = c->d_bpred; p.pose_out = pose_out;
             p.pose_NB = NB; p.pose_bm = ts.bm; p.pose_total = L.groups * mt * ntn;
         }
@@ -337,7 +340,12 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         auto it = c->weights.find(n);
         return it == c->weights.end() ? nullptr : it->second.dev;
     };
-    const bool fold_excite = v.att_source == 1 && c->opt_fold_tails;
+    // Launches are ~6 us each whatever they do; at batch 1 the path is 11 of them around 0.1 ms of work.  Where a launch can be
+    // folded into its neighbour at less than that, small batches do it (measured per batch: profiles/):
+    //   the excitation MLP in the squeeze launch's last workgroup (costs two memory-side round trips per workgroup: +2 us at
+    //   B = 1, +18 us at B = 32), mask + pack inside cnv1's patch fill (level at B = 32).
+    const bool fold_excite = v.att_source == 1 && (c->opt_fold_tails >= 1 || (c->opt_fold_tails < 0 && B <= FOLD_EXCITE_MAX_BATCH));
+    const bool fold_pose = c->opt_fold_tails == 1;
     if (fold_excite) {
         // squeeze + excitation in one launch: the workgroup that delivers a triplet's last partial sum evaluates its tables
         ProfScope ps(c, "se_squeeze_partial");
@@ -361,7 +369,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     // by its byte loads), so the two-kernel form stays the default.  Tuning build: DAVO_FUSE_PACK=1 / DAVO_CNV1_PATCH=0.
     const char* fe = tuning_env("DAVO_FUSE_PACK");
     const char* pe = tuning_env("DAVO_CNV1_PATCH");
-    const bool fuse_env = (fe && atoi(fe) == 1) || c->opt_fuse_pack;
+    const bool fuse_env = (fe && atoi(fe) == 1) || c->opt_fuse_pack == 1 || (c->opt_fuse_pack < 0 && B <= FUSE_PACK_MAX_BATCH);
     const bool patch1 = !(pe && atoi(pe) == 0);
     const bool fused = h3 && patch1 && fuse_env;
     c->packed_valid = !fused;
@@ -393,7 +401,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         if ((rc = run_conv_layer_h3(c, 5, a[4], 256, c->H2, c->W2, a[5], 2 * c6, false, NB))) return rc;
         pose_fused = c->opt_fuse_pose && c->H3 * c->W3 >= 128;
         if ((rc = run_conv_layer_h3(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, true, NB, pose_fused, &pose_bm, &pose_mt, &pose_ntn,
-                                    static_cast<float*>(d_pose)))) return rc;
+                                    fold_pose ? static_cast<float*>(d_pose) : nullptr))) return rc;
         c->cnv7_valid = !pose_fused;
         c->range_dirty = true;
     } else if (c->impl == 0) {
@@ -420,7 +428,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
             if ((rc = run_direct(c, "cnv7", a[5], NB, c->H2, c->W2, c6, 2 * c6, h * c6, hp + "cnv7/weights", hp + "cnv7/biases", 3, 256, 2, 1, a[6], 512, h * 256))) return rc;
         }
     }
-    if (!(pose_fused && c->opt_fold_tails)) {
+    if (!(pose_fused && fold_pose)) {
         ProfScope ps(c, "pose_head");
         if (pose_fused) {
             const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;

@@ -32,7 +32,11 @@ hipError_t launch_m(const ConvParamsH& p, dim3 grid, hipStream_t s) {
     using T = TileH<WM, WN, TM, TN, NSTG>;
     // measured per tile shape (gpurun_out/ab_r02v.log, B=32 and B=128): -3 % on the 256x256 tile (cnv5, cnv6 main launches),
     // -6 % on 256x128 (ab_r02w.log), +15 % on 256x64 (cnv3), +18 % on the 3-slot 128x128 remainder tile, level on 128x128 (cnv4)
-    if constexpr (M16 && !SMALLC && KS == 3 && STRIDE == 1 && layer_rate(LAYER) > 0 && WM == 4 && WN == 2 && TM == 2 && (TN == 4 || TN == 2)) {
+    // ... and the deep-ring 128x128 tile (TM == 1, launches of at most one workgroup per CU): there a chunk is bound by what a CU
+    // can take in from L2 (32 KB per chunk at ~45 GB/s per CU: 0.7 us against 0.3 us of matrix work), and the shared patch
+    // cuts the pixel operand's 16 KB to 5.7 KB
+    if constexpr (M16 && !SMALLC && KS == 3 && STRIDE == 1 && layer_rate(LAYER) > 0 && WM == 4 && WN == 2 &&
+                  ((TM == 2 && (TN == 4 || TN == 2)) || (TM == 1 && TN == 2 && NSTG >= 4))) {
         // shared-tap staging (conv_igemm_h3.h, RATE > 0): one pixel patch per filter row serves its three taps
         constexpr int RATE = layer_rate(LAYER);
         if (p.xs && p.rate == RATE && p.pad_l == RATE && p.pad_t == RATE && p.Hin == p.Hout && p.Win == p.Wout &&
@@ -87,7 +91,10 @@ hipError_t launch_tile_deep(int tile, const ConvParamsH& p, dim3 grid, hipStream
         if (tile == TILE_256x64) return launch_m<KS, STRIDE, 4, 2, 2, 1, LAYER, false, true, 3>(p, grid, s);       // 3 x 40 KB
     if constexpr (MAXBN >= 128) {
         if (tile == TILE_128x128) {
-            if constexpr (LAYER == 7) return launch_m<KS, STRIDE, 2, 2, 2, 2, LAYER, false, true, 4>(p, grid, s);  // 4 x 32 KB
+#ifndef DAVO_DEEP128_WAVES4
+#define DAVO_DEEP128_WAVES4 0   /* measured: eight waves (with the shared patch) 52.4 / 30.6 us for cnv6 / cnv5 at B = 1, four waves 53.7 / 31.2 */
+#endif
+            if constexpr (LAYER == 7 || DAVO_DEEP128_WAVES4) return launch_m<KS, STRIDE, 2, 2, 2, 2, LAYER, false, true, 4>(p, grid, s);  // 4 x 32 KB
             else return launch_m<KS, STRIDE, 4, 2, 1, 2, LAYER, false, true, 4>(p, grid, s);
         }
         if (tile == TILE_256x128) return launch_m<KS, STRIDE, 4, 2, 2, 2, LAYER, false, true, 3>(p, grid, s);      // 3 x 48 KB

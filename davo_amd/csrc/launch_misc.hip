@@ -79,7 +79,7 @@ hipError_t launch_cnv3_patch(const ConvPatchParams& p, int nblk, hipStream_t s) 
 
 hipError_t launch_pose_from_tiles(const float* d_tiles, int NB, int P, int bm, int mtiles, int ntiles_n,
                                   const float* d_bpred, float* d_pose, hipStream_t s) {
-    hipLaunchKernelGGL(pose_from_tiles, dim3((NB * 6 + 63) / 64), dim3(64), 0, s, d_tiles, NB, P, bm, mtiles, ntiles_n, d_bpred, d_pose);
+    hipLaunchKernelGGL(pose_from_tiles, dim3(NB * 6), dim3(64), 0, s, d_tiles, NB, P, bm, mtiles, ntiles_n, d_bpred, d_pose);
     return hipGetLastError();
 }
 

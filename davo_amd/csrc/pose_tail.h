@@ -40,21 +40,38 @@ __device__ __forceinline__ bool last_workgroup(unsigned* counter, unsigned total
     return *ticket_lds == total - 1;
 }
 
-// pose[n][head*3+k] = 0.01 * (bias + (1/P) * sum over the tiles that cover image n); same order as pose_from_tiles
-// (prologue.h): tile-major, N tile minor.  Called by every thread of the last workgroup of a y_mode 2 launch.
+// One wave's sum over the per-tile partial sums that cover image n, head / component hk (partial[head][mtile][ntile][slot][k],
+// slot 0 = the tile's first image, 1 = the next one): entry j = (tile t0 + j / ntn, N tile j % ntn) goes to lane j % 64 (a
+// lane adds its entries in order), then a fixed butterfly over the lanes — the same bits whoever computes it (the
+// pose_from_tiles kernel or the cnv7 launch's last workgroup) and however many lanes hold an entry.  Every lane returns the sum.
+template <bool AGENT>
+__device__ __forceinline__ float pose_tile_sum(const float* __restrict__ partial, int n, int hk, int P, int bm, int mtiles, int ntn, int lane) {
+    const int head = hk / 3, k = hk - head * 3;
+    const int t0 = (n * P) / bm;
+    int t1 = ((n + 1) * P - 1) / bm;
+    if (t1 > mtiles - 1) t1 = mtiles - 1;
+    const int count = (t1 - t0 + 1) * ntn;
+    float tot = 0.f;
+    for (int j = lane; j < count; j += 64) {
+        const int t = t0 + j / ntn, nt = j - (j / ntn) * ntn;
+        const int slot = (t * bm) / P == n ? 0 : 1;
+        const float* pp = partial + (((long)head * mtiles + t) * ntn + nt) * 6 + slot * 3 + k;
+        tot += AGENT ? agent_load(pp) : *pp;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    return tot;
+}
+
+// pose[n][head*3+k] = 0.01 * (bias + (1/P) * sum over the tiles that cover image n); one wave per output, like the
+// pose_from_tiles kernel (prologue.h).  Called by every thread of the last workgroup of a y_mode 2 launch.
 template <int THREADS>
 __device__ __forceinline__ void pose_from_tiles_tail(const ConvParamsH& p) {
-    const int P = p.pose_P, bm = p.pose_bm, mtiles = p.pose_mt, ntn = p.ntiles_n;
-    for (int i = threadIdx.x; i < p.pose_NB * 6; i += THREADS) {
-        const int n = i / 6, hk = i - n * 6, head = hk / 3, k = hk - head * 3;
-        const int t0 = (n * P) / bm, t1 = ((n + 1) * P - 1) / bm;
-        float tot = 0.f;
-        for (int t = t0; t <= t1 && t < mtiles; ++t) {
-            const int slot = (t * bm) / P == n ? 0 : 1;
-            const float* pp = p.pose_partial + (((long)head * mtiles + t) * ntn) * 6 + slot * 3 + k;
-            for (int nt = 0; nt < ntn; ++nt) tot += agent_load(pp + nt * 6);
-        }
-        p.pose_out[i] = 0.01f * (tot / (float)P + p.pose_bias[hk]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < p.pose_NB * 6; i += THREADS / 64) {
+        const int n = i / 6, hk = i - n * 6;
+        const float tot = pose_tile_sum<true>(p.pose_partial, n, hk, p.pose_P, p.pose_bm, p.pose_mt, p.ntiles_n, lane);
+        if (lane == 0) p.pose_out[i] = 0.01f * (tot / (float)p.pose_P + p.pose_bias[hk]);
     }
     if (threadIdx.x == 0) __hip_atomic_store(p.pose_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -324,21 +324,16 @@ __global__ __launch_bounds__(64) void pose_finish(const float* __restrict__ part
 }
 
 // Pose from the per-tile partial sums cnv7's fused epilogue wrote (conv_igemm_h3.h, y_mode 2):
-// partial[head][mtile][ntile][slot][k], slot 0 = the tile's first image, slot 1 = the next one.
+// partial[head][mtile][ntile][slot][k], slot 0 = the tile's first image, slot 1 = the next one.  One 64-lane wave per
+// output (n, head, k): the tiles' terms are spread over the lanes and added by a fixed butterfly (pose_tail.h) — a
+// single thread walking 56 dependent loads (128x32 tiles at batch 1) took 12 us.
 __global__ __launch_bounds__(64) void pose_from_tiles(const float* __restrict__ partial, int NB, int P, int bm,
                                                       int mtiles, int ntiles_n, const float* __restrict__ bpred,
                                                       float* __restrict__ pose /*[2B][6]*/) {
-    const int i = blockIdx.x * 64 + threadIdx.x;           // (n, head, k)
-    if (i >= NB * 6) return;
-    const int n = i / 6, hk = i - n * 6, head = hk / 3, k = hk - head * 3;
-    const int t0 = (n * P) / bm, t1 = ((n + 1) * P - 1) / bm;
-    float tot = 0.f;
-    for (int t = t0; t <= t1 && t < mtiles; ++t) {
-        const int slot = (t * bm) / P == n ? 0 : 1;
-        const float* pp = partial + (((long)head * mtiles + t) * ntiles_n) * 6 + slot * 3 + k;
-        for (int nt = 0; nt < ntiles_n; ++nt) tot += pp[nt * 6];
-    }
-    pose[i] = 0.01f * (tot / (float)P + bpred[hk]);
+    const int i = blockIdx.x;                              // (n, head, k)
+    const int n = i / 6, hk = i - n * 6;
+    const float tot = pose_tile_sum<false>(partial, n, hk, P, bm, mtiles, ntiles_n, threadIdx.x);
+    if (threadIdx.x == 0) pose[i] = 0.01f * (tot / (float)P + bpred[hk]);
 }
 
 // ---- on-device cross-check (impl 1): one thread per output element, reference layouts ----
