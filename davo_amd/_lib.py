@@ -38,7 +38,7 @@ EXPORTS = (
     "davo_last_error", "davo_destroy", "davo_device_malloc", "davo_device_free", "davo_memcpy_h2d",
     "davo_memcpy_d2h", "davo_synchronize", "davo_set_stream", "davo_set_inflight", "davo_profile_enable",
     "davo_profile_reset", "davo_profile_entry", "davo_profile_samples", "davo_last_plan", "davo_set_option", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
-    "davo_host_alloc", "davo_host_free", "davo_calibrate", "davo_activation_range", "davo_set_activation_shifts", "davo_range_stats",
+    "davo_host_alloc", "davo_host_free", "davo_host_register", "davo_host_unregister", "davo_calibrate", "davo_activation_range", "davo_set_activation_shifts", "davo_range_stats",
     "davo_comm_unique_id", "davo_comm_init", "davo_comm_size", "davo_allgather_poses", "davo_allgather_poses_device",
     "davo_comm_allreduce", "davo_comm_barrier", "davo_comm_destroy", "davo_plan_layer",
 )
@@ -114,6 +114,8 @@ def lib():
     L.davo_device_free.argtypes = [vp, vp]
     L.davo_host_alloc.argtypes = [i, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.davo_host_free.argtypes = [vp]
+    L.davo_host_register.argtypes = [i, vp, ctypes.c_size_t]
+    L.davo_host_unregister.argtypes = [vp]
     L.davo_calibrate.argtypes = [vp, i, vp, vp, vp, ctypes.POINTER(i)]
     L.davo_activation_range.argtypes = [vp, f32p, ctypes.POINTER(i), i]
     L.davo_set_activation_shifts.argtypes = [vp, ctypes.POINTER(i)]

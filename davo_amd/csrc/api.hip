@@ -422,6 +422,12 @@ int davo_host_alloc(int device, size_t bytes, void** out) {
     return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? DAVO_OK : DAVO_ERR_HIP;
 }
 int davo_host_free(void* p) { return hipHostFree(p) == hipSuccess ? DAVO_OK : DAVO_ERR_HIP; }
+int davo_host_register(int device, void* p, size_t bytes) {
+    if (!p || bytes == 0) return DAVO_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return DAVO_ERR_HIP;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? DAVO_OK : DAVO_ERR_HIP;
+}
+int davo_host_unregister(void* p) { return hipHostUnregister(p) == hipSuccess ? DAVO_OK : DAVO_ERR_HIP; }
 
 int davo_device_malloc(davo_ctx* c, size_t bytes, void** out) {
     if (!c || !out) return DAVO_ERR_INVALID;
@@ -559,6 +565,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "fuse_pack") c->opt_fuse_pack = value < 0 ? -1 : (value != 0);
     else if (k == "share_taps") c->opt_share_taps = value != 0;
     else if (k == "merge_rem") c->opt_merge_rem = value != 0;
+    else if (k == "merge_cnv4") c->opt_merge_cnv4 = value != 0;
     else if (k == "patch_cnv2") c->opt_patch_cnv2 = value != 0;
     else if (k == "patch_cnv3") c->opt_patch_cnv3 = value != 0;
     else if (k == "fold_tails") c->opt_fold_tails = value < 0 ? -1 : (value > 2 ? 1 : value);

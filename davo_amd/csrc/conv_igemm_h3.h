@@ -836,7 +836,8 @@ void conv_igemm_h3(ConvParamsH p) {
 // remainder's workgroups, a multiple of 32): each engine's eight CUs start with four of each.  Then the rest of the main
 // tiles, then the second half of the remainder.  Ordinals keep id % 8, so xcd_remap still gives each XCD a contiguous run
 // of each kind.
-template <int LAYER, int RATE>
+// TNM: N extent of the main tile in 64-column units per wave pair: 4 = 256x256 (cnv5, cnv6), 2 = 256x128 (cnv4, 128 output channels).
+template <int LAYER, int RATE, int TNM = 4>
 __global__ __launch_bounds__(512, 2) void conv_igemm_h3_mainrem(ConvParamsH pm, ConvParamsH pr, int n_main, int n_rem) {
     const int b = blockIdx.x, h = n_rem >> 1;
     int ord;
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3_mainrem(ConvParamsH pm, 
     else if (b < h + n_main) { rem = false; ord = b - h; }
     else { rem = true; ord = b - n_main; }
     if (rem) conv_igemm_h3_body<3, 1, 4, 2, 1, 2, LAYER, true, false, true, 3, 0>(pr, ord, n_rem, 0);
-    else conv_igemm_h3_body<3, 1, 4, 2, 2, 4, LAYER, true, false, true, 2, RATE>(pm, ord, n_main, 0);
+    else conv_igemm_h3_body<3, 1, 4, 2, 2, TNM, LAYER, true, false, true, 2, RATE>(pm, ord, n_main, 0);
 }
 
 #undef H3_DBG

@@ -200,13 +200,24 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         if (pose_ntn) *pose_ntn = ntn;
     }
     c->last_plan[li][0] = c->last_plan[li][1] = 0;
-    if (c->opt_merge_rem && !fuse_pose && plan.size() == 2 && plan[0].tile == TILE_256x256 && plan[1].tile == TILE_128x128 &&
-        L.groups == 1 && L.npad_h == 256 && c->ncu == 256 && !tuning_env("DAVO_NO_MERGE")) {
+    if (c->opt_merge_cnv4 && c->opt_merge_rem && li == 3 && !fuse_pose && L.npad_h == 128 && L.groups == 1 && c->ncu == 256 && L.tile_h < 0 &&
+        plan.size() == 1 && plan[0].tile == TILE_128x128) {
+        // cnv4 (N = 128): whole rounds of 256x128 tiles (shared-tap staging, twice the matrix work per staged byte of the
+        // 128x128 tile) + the remaining rows on 128x128 tiles, as one grid like cnv5 / cnv6 below
+        const int rows1 = (p.M / 256 / c->ncu) * c->ncu * 256;
+        const int rem = p.M - rows1, n_rem = (rem + 127) / 128;
+        if (rows1 > 0 && rem > 0 && rem % 128 == 0 && n_rem % 64 == 0 && n_rem <= 256)
+            plan = {{0, rows1, TILE_256x128}, {rows1, rem, TILE_128x128}};
+    }
+    const bool merge_256 = plan.size() == 2 && plan[0].tile == TILE_256x256 && plan[1].tile == TILE_128x128 && L.npad_h == 256;
+    const bool merge_128 = plan.size() == 2 && plan[0].tile == TILE_256x128 && plan[1].tile == TILE_128x128 && L.npad_h == 128;
+    if (c->opt_merge_rem && !fuse_pose && (merge_256 || merge_128) && L.groups == 1 && c->ncu == 256 && !tuning_env("DAVO_NO_MERGE")) {
         // main + remainder as one grid (conv_igemm_h3_mainrem): same tiles, same arithmetic, de-phased store bursts
         ConvParamsH pm = p, pr = p;
+        const int rem_ntn = L.npad_h / 128;                       // N tiles of a 128x128 remainder row block
         pm.ntiles_n = 1; pm.mtile0 = 0; pm.M = plan[0].rows;
-        pr.ntiles_n = 2; pr.mtile0 = plan[1].row0 / 128; pr.M = plan[1].row0 + plan[1].rows;
-        const int n_main = plan[0].rows / 256, n_rem = ((plan[1].rows + 127) / 128) * 2;
+        pr.ntiles_n = rem_ntn; pr.mtile0 = plan[1].row0 / 128; pr.M = plan[1].row0 + plan[1].rows;
+        const int n_main = plan[0].rows / 256, n_rem = ((plan[1].rows + 127) / 128) * rem_ntn;
         // the shape test comes first: a profiling scope is opened only around a launch that is really issued
         // (an empty event pair under the layer's label would halve its average and advance the stride counter twice)
         if (layer_h3_mainrem_supported(li, pm, n_main, n_rem)) {

@@ -32,17 +32,17 @@ bool mainrem_ok(const ConvParamsH& pm, int n_main, int n_rem) {
     return !(n_rem < 64 || n_rem % 64 || n_rem > 256 || n_main < n_rem / 2 || n_main % 8);
 }
 
-template <int LAYER>
+template <int LAYER, int TNM = 4>
 hipError_t launch_mainrem(const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, hipStream_t s) {
     using namespace h3impl;
     constexpr int RATE = layer_rate(LAYER);
-    using TM_ = TileH<4, 2, 2, 4, 2>;
-    using TX = TileX<4, 2, 2, 4, 2, RATE>;
+    using TM_ = TileH<4, 2, 2, TNM, 2>;
+    using TX = TileX<4, 2, 2, TNM, 2, RATE>;
     using TR = TileH<4, 2, 1, 2, DAVO_REM_STAGES>;
     static_assert(DAVO_REM_STAGES == 3, "conv_igemm_h3_mainrem instantiates the three-slot remainder tile");
     if (!mainrem_ok<LAYER>(pm, n_main, n_rem)) return hipErrorNotSupported;
     constexpr int lds = TX::LDS_BYTES > TR::LDS_BYTES_DMA ? TX::LDS_BYTES : TR::LDS_BYTES_DMA;
-    auto kern = conv_igemm_h3_mainrem<LAYER, RATE>;
+    auto kern = conv_igemm_h3_mainrem<LAYER, RATE, TNM>;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_main + n_rem), dim3(TM_::THREADS), lds, s, pm, pr, n_main, n_rem);
@@ -52,12 +52,14 @@ hipError_t launch_mainrem(const ConvParamsH& pm, int n_main, const ConvParamsH& 
 }  // namespace
 
 bool layer_h3_mainrem_supported(int layer, const ConvParamsH& pm, int n_main, int n_rem) {
+    if (layer == 3) return mainrem_ok<4>(pm, n_main, n_rem);
     if (layer == 4) return mainrem_ok<5>(pm, n_main, n_rem);
     if (layer == 5) return mainrem_ok<6>(pm, n_main, n_rem);
     return false;
 }
 
 hipError_t launch_layer_h3_mainrem(int layer, const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, hipStream_t s) {
+    if (layer == 3) return launch_mainrem<4, 2>(pm, n_main, pr, n_rem, s);     // cnv4: 256x128 main tiles (N = 128)
     if (layer == 4) return launch_mainrem<5>(pm, n_main, pr, n_rem, s);
     if (layer == 5) return launch_mainrem<6>(pm, n_main, pr, n_rem, s);
     return hipErrorNotSupported;

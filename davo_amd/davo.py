@@ -54,6 +54,19 @@ def pinned_empty(shape, dtype, device=0):
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
+def pin_array(arr, device=0):
+    """Page-lock the memory of a C-contiguous numpy array in place (include/davo_hip.h: davo_host_register)."""
+    if not arr.flags.c_contiguous:
+        raise ValueError("only a C-contiguous array can be page-locked in place")
+    if _lib.lib().davo_host_register(int(device), ctypes.c_void_p(arr.ctypes.data), arr.nbytes) != 0:
+        raise DavoError("davo_host_register(%d bytes) failed on device %d" % (arr.nbytes, device))
+
+
+def unpin_array(arr):
+    if _lib.lib().davo_host_unregister(ctypes.c_void_p(arr.ctypes.data)) != 0:
+        raise DavoError("davo_host_unregister failed")
+
+
 class DeviceBuffer:
     """A hipMalloc'd buffer owned through a context (bench / multi-GPU shards keep inputs in HBM)."""
 

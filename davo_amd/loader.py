@@ -43,17 +43,31 @@ def load_window(dump_dir, seq, tgt_idx, H, W):
     return img, flow, seg
 
 
-def _read_npy_into(path, dst):
+def _read_npy_into(path, dst, planes=None):
     """Read a C-ordered .npy of dst's dtype and size straight into dst (no intermediate array); anything else
-    goes through np.load + cast."""
+    goes through np.load + cast.  ``planes``: indices along the first axis that are wanted — the others are skipped
+    in the file (seek) and left as they are in dst (the path reads flow planes 0,1 and the source frames' label maps only:
+    davo.py:978-982,998-1004, so 1.3 of a window's 2.3 MB never have to leave the page cache)."""
     with open(path, "rb") as f:
         major, _ = np.lib.format.read_magic(f)
         shape, fortran, dtype = (np.lib.format.read_array_header_1_0 if major == 1 else np.lib.format.read_array_header_2_0)(f)
         if not fortran and dtype == dst.dtype and int(np.prod(shape)) == dst.size and dst.flags.c_contiguous:
-            if f.readinto(memoryview(dst).cast("B")) != dst.nbytes:
-                raise ValueError("%s is truncated" % path)
+            if planes is None:
+                if f.readinto(memoryview(dst).cast("B")) != dst.nbytes:
+                    raise ValueError("%s is truncated" % path)
+                return
+            base, per = f.tell(), dst[0].nbytes
+            for k in planes:
+                f.seek(base + k * per)
+                if f.readinto(memoryview(dst[k]).cast("B")) != per:
+                    raise ValueError("%s is truncated" % path)
             return
-    dst[...] = np.load(path).astype(dst.dtype, copy=False).reshape(dst.shape)
+    a = np.load(path).astype(dst.dtype, copy=False).reshape(dst.shape)
+    if planes is None:
+        dst[...] = a
+    else:
+        for k in planes:
+            dst[k] = a[k]
 
 
 def _decode_jpeg(path):
@@ -82,8 +96,13 @@ class JpegDecodePool:
         self.pool.shutdown(wait=False, cancel_futures=True)
 
 
-def load_window_into(dump_dir, seq, tgt_idx, H, W, img, flow, seg, decoder=None):
-    """load_window writing into the caller's [H,3W,3] / [4,H,W,2] / [3,H,W,1] slots."""
+FLOW_PLANES_USED = (0, 1)           # davo.py:978-982: pred_flows = [0, flow[:,0], flow[:,1]]
+SEG_PLANES_SOURCES = (0, 2)         # davo.py:998-1004 + 1408-1412: the target frame's attention is overwritten by ones
+
+
+def load_window_into(dump_dir, seq, tgt_idx, H, W, img, flow, seg, decoder=None, flow_planes=None, seg_planes=None):
+    """load_window writing into the caller's [H,3W,3] / [4,H,W,2] / [3,H,W,1] slots; ``flow_planes`` / ``seg_planes``
+    restrict the .npy reads to the planes the variant consumes (None = all)."""
     jpg, flo, sg = window_paths(dump_dir, seq, tgt_idx)
     if decoder is None:
         from PIL import Image
@@ -94,8 +113,8 @@ def load_window_into(dump_dir, seq, tgt_idx, H, W, img, flow, seg, decoder=None)
     if a.shape != (H, 3 * W, 3):
         raise ValueError("%s is %s, expected %s" % (jpg, a.shape, (H, 3 * W, 3)))
     img[...] = a
-    _read_npy_into(flo, flow)
-    _read_npy_into(sg, seg)
+    _read_npy_into(flo, flow, flow_planes)
+    _read_npy_into(sg, seg, seg_planes)
 
 
 def count_frames(dump_dir, seq, seq_length=3):
@@ -195,6 +214,178 @@ class ThreadedWindowLoader:
                 t.join(timeout=0.05)
             if self.on_close is not None:
                 self.on_close()
+
+
+# ---- worker processes that fill shared batch buffers --------------------------------------------------------------
+_W = {}                              # per worker process: the attached buffer ring and the dump it reads
+
+
+def _proc_init(names, B, H, W, dump_dir, seq, flow_planes, seg_planes):
+    from multiprocessing import shared_memory
+    ring = []
+    for trio in names:
+        # spawned workers report to the parent's resource tracker, where these names are registered already (a set): attaching
+        # changes nothing there, and the parent's close() is what unlinks the segments
+        segs = [shared_memory.SharedMemory(name=n) for n in trio]
+        ring.append((segs, (np.ndarray((B, H, 3 * W, 3), np.uint8, buffer=segs[0].buf),
+                            np.ndarray((B, 4, H, W, 2), np.float32, buffer=segs[1].buf),
+                            np.ndarray((B, 3, H, W, 1), np.float32, buffer=segs[2].buf))))
+    _W.update(ring=ring, dump=dump_dir, seq=seq, H=H, W=W, fp=flow_planes, sp=seg_planes)
+
+
+def _proc_fill(ring_idx, slot0, w0, n):
+    """windows w0 .. w0+n-1 (target frames w+1) into slots slot0.. of buffer set ring_idx; returns n"""
+    img, flow, seg = _W["ring"][ring_idx][1]
+    for j in range(n):
+        load_window_into(_W["dump"], _W["seq"], w0 + j + 1, _W["H"], _W["W"], img[slot0 + j], flow[slot0 + j], seg[slot0 + j],
+                         None, _W["fp"], _W["sp"])
+    return n
+
+
+class ProcessWindowLoader:
+    """Batches of windows [lo, hi) in order, filled by ``procs`` worker PROCESSES that decode the strip and read the
+    .npy planes of whole windows straight into shared-memory batch buffers (data_loader.py:241-325's pipeline with
+    processes where TF has native threads: Pillow decodes under the GIL, so threads give one core's worth of JPEG).
+    The parent never touches a pixel: it hands out (buffer set, slot range, window range) tasks of ``chunk`` windows
+    and yields a batch when its tasks are done.  ``pin(array)`` / ``unpin(array)`` page-lock the buffers for the H2D DMA
+    (davo_amd.pin_array: hipHostRegister over the shared mapping).  Only the flow planes and label maps the variant
+    consumes are read; the rest of a slot keeps its zeros.  Start method "spawn": the parent may hold a HIP context.
+
+    A batch is valid until the consumer asks for the next one; the last one until ``close()`` (or the loader's deletion),
+    which unpins and unmaps the buffers.  The end of iteration stops the workers and removes the segments' names."""
+
+    def __init__(self, dump_dir, seq, H, W, lo, hi, batch_size, procs=8, prefetch=2, chunk=None, pin=None, unpin=None,
+                 flow_planes=FLOW_PLANES_USED, seg_planes=SEG_PLANES_SOURCES):
+        self.args = (dump_dir, seq, H, W)
+        self.lo, self.hi, self.B = lo, hi, batch_size
+        self.procs, self.prefetch = max(1, procs), max(1, prefetch)
+        self.chunk = chunk or max(1, min(8, -(-batch_size // self.procs)))
+        self.pin, self.unpin, self.fp, self.sp = pin, unpin, flow_planes, seg_planes
+        self._segs, self._views, self._pool, self._pinned, self._unlinked = [], [], None, [], []
+
+    def __len__(self):
+        return -(-(self.hi - self.lo) // self.B)
+
+    def _open(self):
+        self.close()                                      # a second iteration starts from fresh buffers
+        import multiprocessing as mp
+        from multiprocessing import shared_memory
+        dump_dir, seq, H, W = self.args
+        B = self.B
+        FILL = 2
+        self.nring = self.prefetch + FILL + 2
+        sizes = (B * H * 3 * W * 3, B * 4 * H * W * 2 * 4, B * 3 * H * W * 4)
+        for _ in range(self.nring):
+            trio = [shared_memory.SharedMemory(create=True, size=max(n, 1)) for n in sizes]
+            self._segs.append(trio)
+            views = (np.ndarray((B, H, 3 * W, 3), np.uint8, buffer=trio[0].buf),
+                     np.ndarray((B, 4, H, W, 2), np.float32, buffer=trio[1].buf),
+                     np.ndarray((B, 3, H, W, 1), np.float32, buffer=trio[2].buf))
+            self._views.append(views)
+            if self.pin is not None:
+                for v in views:
+                    self.pin(v)
+                    self._pinned.append(v)
+        names = [[sm.name for sm in trio] for trio in self._segs]
+        self._pool = ProcessPoolExecutor(self.procs, mp_context=mp.get_context("spawn"), initializer=_proc_init,
+                                         initargs=(names, B, H, W, dump_dir, seq, self.fp, self.sp))
+
+    def _stop(self):
+        """end of iteration: no more tasks; the names leave /dev/shm (nothing leaks if the process dies from here on) while
+        the mappings - and with them the last batch the consumer may still hold - stay valid until close()"""
+        if self._pool is not None:
+            self._pool.shutdown(wait=True, cancel_futures=True)
+            self._pool = None
+        for trio in self._segs:
+            for sm in trio:
+                if sm not in self._unlinked:
+                    self._unlinked.append(sm)
+                    try:
+                        sm.unlink()
+                    except OSError:
+                        pass
+
+    def close(self):
+        """unpin and unmap the batch buffers: every array this loader has yielded is invalid afterwards (numpy does not keep
+        a shared-memory mapping alive).  Called by __del__; iteration itself only stops the workers (_stop)."""
+        self._stop()
+        if self.unpin is not None:
+            for v in self._pinned:
+                try:
+                    self.unpin(v)
+                except Exception:                         # noqa: BLE001 — teardown must reach the unmap below
+                    pass
+        self._pinned = []
+        self._views = []
+        for trio in self._segs:
+            for sm in trio:
+                try:
+                    sm.close()
+                except (OSError, BufferError):
+                    pass
+        self._segs, self._unlinked = [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                 # noqa: BLE001 — interpreter teardown
+            pass
+
+    def __iter__(self):
+        self._open()
+        q = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+        FILL = 2
+
+        def producer():
+            turn = 0
+            try:
+                starts = iter(range(self.lo, self.hi, self.B))
+                pending = collections.deque()
+                while True:
+                    while len(pending) < FILL:
+                        s = next(starts, None)
+                        if s is None:
+                            break
+                        e = min(s + self.B, self.hi)
+                        ridx = turn % self.nring
+                        turn += 1
+                        futs = [self._pool.submit(_proc_fill, ridx, w - s, w, min(self.chunk, e - w)) for w in range(s, e, self.chunk)]
+                        pending.append((s, e, ridx, futs))
+                    if not pending or stop.is_set():
+                        break
+                    s, e, ridx, futs = pending.popleft()
+                    for f in futs:
+                        f.result()
+                    q.put((s, e, tuple(v[:e - s] for v in self._views[ridx]), None))
+                for _, _, _, futs in pending:
+                    for f in futs:
+                        f.cancel()
+            except BaseException as exc:            # noqa: BLE001 — hand the failure to the consumer
+                q.put((None, None, None, exc))
+                return
+            q.put(None)
+
+        t = threading.Thread(target=producer, daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                s, e, batch, exc = item
+                if exc is not None:
+                    raise exc
+                yield s, e, batch
+        finally:
+            stop.set()
+            while t.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                t.join(timeout=0.05)
+            self._stop()
 
 
 def kitti_loader(dump_dir, seq, H, W, lo, hi, batch_size, workers=4, prefetch=2, alloc=None, decode_procs=0):

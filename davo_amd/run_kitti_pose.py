@@ -45,7 +45,14 @@ def main(argv=None):
                     help="skip the activation-range calibration of the f16x3 arithmetic (include/davo_hip.h: davo_calibrate)")
     ap.add_argument("--loader_threads", type=int, default=4, help="decode/read threads of the input pipeline (as data_loader.py:283-288; more threads contend on the GIL)")
     ap.add_argument("--decode_procs", type=int, default=0,
-                    help="extra JPEG decode processes, for Pillow builds that hold the GIL while decoding; 0 = decode in the loader threads")
+                    help="(threaded loader) extra JPEG decode processes; 0 = decode in the loader threads")
+    ap.add_argument("--loader_procs", type=int, default=-1,
+                    help="worker processes that decode the strips and read the .npy planes straight into shared, page-locked batch "
+                         "buffers (davo_amd/loader.py: ProcessWindowLoader).  -1 = this rank's CPU share minus two, at most 12; "
+                         "0 = the threaded loader (--loader_threads)")
+    ap.add_argument("--force_comm", action="store_true",
+                    help="build the RCCL communicator and run the pose all-gather at world size 1 too (exercises the multi-GPU path on one GPU)")
+    ap.add_argument("--report", default=None, help="write the run's time split (load wait / forward / gather / stitch / write) as JSON here")
     a = ap.parse_args(argv)
 
     from .comm import RcclComm, world_from_env
@@ -68,10 +75,24 @@ def main(argv=None):
         from glob import glob
         d = os.path.join(a.concat_img_dir, "%.2d" % a.test_seq)
         n_frames = len(glob(d + "/*.jpg")) + 2 * int((a.seq_length - 1) / 2)      # test_kitti_pose.py:81-82
-        from .davo import pinned_empty                   # batches are decoded straight into page-locked memory
+        from .davo import pinned_empty, pin_array, unpin_array    # batches are decoded straight into page-locked memory
+        procs = a.loader_procs
+        if procs < 0:
+            cores = len(os.sched_getaffinity(0))
+            try:
+                q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    cores = min(cores, max(1, int(int(q) / int(period))))
+            except (OSError, ValueError):
+                pass
+            procs = max(1, min(12, cores - 2))
+        from .version import parse_version
+        static_all = parse_version(a.version).att_source == "static_all"   # only -segmask_all-static reads the target frame's label map
         load = S.kitti_window_loader(a.concat_img_dir, a.test_seq, n_frames, H, W,
                                      alloc=lambda shape, dtype: pinned_empty(shape, dtype, device_index),
-                                     workers=a.loader_threads, decode_procs=a.decode_procs)
+                                     workers=a.loader_threads, decode_procs=a.decode_procs, procs=procs,
+                                     pin=lambda arr: pin_array(arr, device_index), unpin=unpin_array,
+                                     seg_planes=(0, 1, 2) if static_all else None)
         from .tf_checkpoint import load_weights
         weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
 
@@ -83,16 +104,28 @@ def main(argv=None):
         # every rank calibrates on the same first windows, so the trajectory does not depend on the world size
         system.calibrate(load(0, min(a.batch_size, n_frames - 2)))
 
-    comm = RcclComm.from_env(system.engine) if world > 1 else None      # collective; fails loudly, no other transport
+    comm = RcclComm.from_env(system.engine) if (world > 1 or a.force_comm) else None      # collective; fails loudly, no other transport
     t0 = time.perf_counter()
-    traj, poses = S.run_sequence(infer, load, n_frames, a.batch_size, rank, world, comm)
+    timing = {}
+    traj, poses = S.run_sequence(infer, load, n_frames, a.batch_size, rank, world, comm, timing)
     dt = time.perf_counter() - t0
     if rank == 0:
         os.makedirs(a.output_dir, exist_ok=True)
         out = os.path.join(a.output_dir, "%.2d-pred_kitti_pose.txt" % a.test_seq)   # :116
+        tw = time.perf_counter()
         S.write_kitti_poses(out, traj)
-        print("Done. Please check %s  (%d windows on %d GPU(s) in %.2f s incl. input generation/IO)"
-              % (out, n_frames - 2, world, dt))
+        timing["write_s"] = time.perf_counter() - tw
+        timing.update(total_s=dt + timing["write_s"], windows=n_frames - 2, world=world, batch_size=a.batch_size,
+                      windows_per_s=(n_frames - 2) / dt, range_recovery=system.engine.range_stats(),
+                      note="rank 0's seconds; load_wait_s = time the GPU side waited for the input pipeline, forward_s = H2D + kernels + "
+                           "pose D2H inside DAVO.inference, gather_s = the RCCL all-gather incl. staging")
+        print("Done. Please check %s  (%d windows on %d GPU(s) in %.2f s incl. input generation/IO: input wait %.2f, forward %.2f, "
+              "gather %.3f, stitch %.2f, write %.2f)" % (out, n_frames - 2, world, dt, timing["load_wait_s"], timing["forward_s"],
+                                                         timing["gather_s"], timing["stitch_s"], timing["write_s"]))
+        if a.report:
+            import json
+            with open(a.report, "w") as f:
+                json.dump({k: (round(v, 4) if isinstance(v, float) else v) for k, v in timing.items()}, f)
     if comm is not None:
         comm.barrier()
         comm.close()

@@ -12,6 +12,8 @@ the only exchange is one all-gather of ``[n,2,6]`` float32 before the sequential
 """
 import os
 
+import time
+
 import numpy as np
 
 
@@ -125,7 +127,7 @@ def _pad_batch(img, flow, seg, batch_size):
     return img, flow, seg, n
 
 
-def run_shard(infer_fn, load_windows, lo, hi, batch_size):
+def run_shard(infer_fn, load_windows, lo, hi, batch_size, timing=None):
     """Run windows [lo,hi) in batches; the last batch is padded by repeating its last window
     and the padded outputs are dropped (the reference's complete_batch_size,
     utils/common_utils.py:8-13, would append duplicate poses for B>1; parity is defined on
@@ -133,15 +135,28 @@ def run_shard(infer_fn, load_windows, lo, hi, batch_size):
 
     ``load_windows`` is either a callable ``(s, e) -> (img, flow, seg)`` or an iterable of
     ``(s, e, (img, flow, seg))`` in window order (davo_amd.loader.ThreadedWindowLoader: the next
-    batches are decoded while this one is on the GPU)."""
+    batches are decoded while this one is on the GPU).  ``timing`` (a dict) receives the seconds spent waiting for
+    input and inside ``infer_fn``."""
     out = np.zeros((hi - lo, 2, 6), np.float32)
     if callable(load_windows):
         batches = ((s, min(s + batch_size, hi), load_windows(s, min(s + batch_size, hi))) for s in range(lo, hi, batch_size))
     else:
         batches = iter(load_windows)
-    for s, e, (img, flow, seg) in batches:
+    t_load = t_fwd = 0.0
+    while True:
+        t0 = time.perf_counter()
+        item = next(batches, None)                       # with a prefetching loader: the time the GPU side WAITED for input
+        t1 = time.perf_counter()
+        t_load += t1 - t0
+        if item is None:
+            break
+        s, e, (img, flow, seg) = item
         img, flow, seg, n = _pad_batch(img, flow, seg, batch_size)
         out[s - lo:e - lo] = np.asarray(infer_fn(img, flow, seg))[:n]
+        t_fwd += time.perf_counter() - t1
+    if timing is not None:
+        timing["load_wait_s"] = timing.get("load_wait_s", 0.0) + t_load
+        timing["forward_s"] = timing.get("forward_s", 0.0) + t_fwd       # H2D copies + kernels + D2H of the poses (davo_forward)
     return out
 
 
@@ -151,7 +166,7 @@ def gather_poses(local, n_windows, world, rank, comm=None):
     ``comm`` is the run's communicator: ``davo_amd.comm.RcclComm`` (librccl through the C ABI,
     include/davo_hip.h: davo_allgather_poses) in the product; anything with the same
     ``allgather(local, n_per_rank) -> (all, ms)`` in the CPU tests of the sharding logic."""
-    if world == 1:
+    if world == 1 and comm is None:
         return np.asarray(local, np.float32)
     if comm is None:
         raise ValueError("world size %d needs a communicator (davo_amd.comm.RcclComm)" % world)
@@ -165,16 +180,22 @@ def gather_poses(local, n_windows, world, rank, comm=None):
     return np.concatenate(parts, 0)
 
 
-def run_sequence(infer_fn, load_windows, n_frames, batch_size, rank=0, world=1, comm=None):
+def run_sequence(infer_fn, load_windows, n_frames, batch_size, rank=0, world=1, comm=None, timing=None):
     """The driver loop of test_kitti_pose.py:133-149, sharded: returns the Nf 4x4 poses on
-    every rank (the stitch is cheap and sequential; rank 0 writes the file)."""
+    every rank (the stitch is cheap and sequential; rank 0 writes the file).  ``timing`` (a dict) receives this
+    rank's seconds per stage: load_wait_s, forward_s, gather_s, stitch_s."""
     n_windows = n_frames - 2
     lo, hi = shard_windows(n_windows, world, rank)
     if hasattr(load_windows, "for_range"):               # a loader factory: build this rank's prefetching loader
         load_windows = load_windows.for_range(lo, hi, batch_size)
-    local = run_shard(infer_fn, load_windows, lo, hi, batch_size)
+    local = run_shard(infer_fn, load_windows, lo, hi, batch_size, timing)
+    t0 = time.perf_counter()
     poses = gather_poses(local, n_windows, world, rank, comm)
-    return stitch_trajectory(poses), poses
+    t1 = time.perf_counter()
+    traj = stitch_trajectory(poses)
+    if timing is not None:
+        timing.update(gather_s=t1 - t0, stitch_s=time.perf_counter() - t1, windows_this_rank=hi - lo)
+    return traj, poses
 
 
 # ---- on-disk inputs (data_loader.py:241-325; doc/preprocessing.md:50-114) -------------------
@@ -182,13 +203,19 @@ class kitti_window_loader:
     """Loader factory over the reference's dump (davo_amd/loader.py): ``for_range(lo, hi, B)`` gives the
     threaded, prefetching batch iterator of a rank's shard; calling it ``(s, e)`` loads one batch inline."""
 
-    def __init__(self, concat_img_dir, seq, n_frames, H, W, workers=4, prefetch=2, alloc=None, decode_procs=0):
+    def __init__(self, concat_img_dir, seq, n_frames, H, W, workers=4, prefetch=2, alloc=None, decode_procs=0, procs=0,
+                 pin=None, unpin=None, seg_planes=None):
         self.dir, self.seq, self.n_frames, self.H, self.W = concat_img_dir, seq, n_frames, H, W
         self.workers, self.prefetch, self.alloc, self.decode_procs = workers, prefetch, alloc, decode_procs
+        self.procs, self.pin, self.unpin, self.seg_planes = procs, pin, unpin, seg_planes
 
     def for_range(self, lo, hi, batch_size):
-        from .loader import kitti_loader
-        return kitti_loader(self.dir, self.seq, self.H, self.W, lo, hi, batch_size, self.workers, self.prefetch, self.alloc, self.decode_procs)
+        from . import loader as L
+        if self.procs > 0:      # worker processes fill shared (page-locked) batch buffers: davo_amd/loader.py, ProcessWindowLoader
+            return L.ProcessWindowLoader(self.dir, self.seq, self.H, self.W, lo, hi, batch_size, self.procs, self.prefetch,
+                                         pin=self.pin, unpin=self.unpin,
+                                         seg_planes=L.SEG_PLANES_SOURCES if self.seg_planes is None else self.seg_planes)
+        return L.kitti_loader(self.dir, self.seq, self.H, self.W, lo, hi, batch_size, self.workers, self.prefetch, self.alloc, self.decode_procs)
 
     def __call__(self, s, e):
         from .loader import load_window

@@ -99,6 +99,11 @@ int davo_device_free(davo_ctx* ctx, void* p);
  * overlaps the kernels of the previous sub-batch.  Pageable buffers work too, just slower. */
 int davo_host_alloc(int device, size_t bytes, void** out);
 int davo_host_free(void* p);
+/* Page-lock memory the caller already owns (hipHostRegister), e.g. the shared-memory batch buffers that the input
+ * pipeline's worker processes decode into (davo_amd/loader.py: ProcessWindowLoader); undo with davo_host_unregister
+ * before the memory is unmapped. */
+int davo_host_register(int device, void* p, size_t bytes);
+int davo_host_unregister(void* p);
 int davo_memcpy_h2d(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
 int davo_memcpy_d2h(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* Waits for every stream of the context, then gives the f16x3 batches issued through

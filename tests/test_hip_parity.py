@@ -1170,3 +1170,32 @@ def test_pose_is_identical_launch_after_launch(B, tile):
             bad += 1
     assert bad == 0, "%d of 199 forwards differ from the first" % bad
     e.close()
+
+
+def test_config4_shape_from_files_one_rank_with_forced_gather(tmp_path, c_oracle):
+    """BASELINE configs[3] plumbing on one GPU: a dump on disk -> worker processes decoding into shared page-locked batch
+    buffers (the default loader of the CLI) -> batch 64 -> the RCCL all-gather at world size 1 (--force_comm) -> stitch ->
+    trajectory file == the oracle on the same decoded files; the run's time split is reported."""
+    import json
+    from davo_amd import run_kitti_pose, sequence as S, loader as L
+    dump = str(tmp_path / "dump")
+    n_frames = 150
+    L.write_synthetic_dump(dump, 0, n_frames, 64, 96)
+    cfg = parse_version(FLAGSHIP_VERSION)
+    weights = synth.make_weights(cfg)
+    np.savez(str(tmp_path / "w.npz"), **weights)
+    report = str(tmp_path / "report.json")
+    run_kitti_pose.main(["--concat_img_dir", dump, "--ckpt_file", str(tmp_path / "w.npz"), "--output_dir", str(tmp_path),
+                         "--test_seq", "0", "--batch_size", "64", "--img_height", "64", "--img_width", "96", "--loader_procs", "3",
+                         "--force_comm", "--report", report])
+    got = S.read_kitti_poses(str(tmp_path / "00-pred_kitti_pose.txt"))
+    infer = lambda img, flow, seg: c_oracle.forward(cfg, img, flow, seg, weights)   # noqa: E731
+    want, _ = S.run_sequence(infer, S.kitti_window_loader(dump, 0, n_frames, 64, 96).__call__, n_frames, 64)
+    assert got.shape == (n_frames, 4, 4)
+    assert np.abs(got - np.array(want)).max() < 2e-3                      # a 148-step chain of float32-grade poses
+    r = json.load(open(report))
+    assert r["windows"] == n_frames - 2 and r["world"] == 1 and r["batch_size"] == 64
+    for k in ("load_wait_s", "forward_s", "gather_s", "stitch_s", "write_s", "total_s"):
+        assert r[k] >= 0.0
+    assert r["forward_s"] > 0 and r["total_s"] >= r["forward_s"] and r["range_recovery"]["f32_batches"] == 0
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("psm_")]

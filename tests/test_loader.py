@@ -107,3 +107,58 @@ def test_run_sequence_with_prefetching_loader_matches_inline(dump, c_oracle):
     traj_a, poses_a = S.run_sequence(infer, fac, 9, 3)                       # threaded loader (factory)
     traj_b, poses_b = S.run_sequence(infer, fac.__call__, 9, 3)              # inline (callable) form
     assert np.array_equal(poses_a, poses_b) and len(traj_a) == 9
+
+
+def test_process_loader_fills_shared_buffers_with_the_planes_the_path_reads(dump):
+    """ProcessWindowLoader: worker processes decode whole windows into shared-memory batch buffers; batches arrive in
+    order, the strip and the consumed planes (flow 0,1; label maps of the two source frames) equal the inline loads,
+    the planes the path never reads (davo.py:978-982,998-1004) are not touched, and the segments are gone afterwards."""
+    d, n_windows, H, W = dump, 7, 32, 64
+    ref = {w: L.load_window(d, 3, w + 1, H, W) for w in range(n_windows)}
+    for B, procs, chunk in ((4, 2, None), (5, 3, 2)):
+        ld = L.ProcessWindowLoader(d, 3, H, W, 0, n_windows, B, procs=procs, prefetch=1, chunk=chunk)
+        seen = []
+        for s, e, (img, flow, seg) in ld:
+            assert img.shape == (e - s, H, 3 * W, 3) and s == (seen[-1] if seen else 0)
+            for i, w in enumerate(range(s, e)):
+                assert np.array_equal(img[i], ref[w][0])
+                assert np.array_equal(flow[i, :2], ref[w][1][:2]) and np.array_equal(seg[i, [0, 2]], ref[w][2][[0, 2]])
+                assert not flow[i, 2:].any() and not seg[i, 1].any()
+            seen.append(e)
+        assert seen[-1] == n_windows and len(seen) == -(-n_windows // B)
+        assert ld._pool is None and not any(os.path.exists("/dev/shm/" + sm.name.lstrip("/")) for trio in ld._segs for sm in trio)
+        ld.close()
+        assert ld._segs == []
+    # every plane on request (the -segmask_all-static variant reads the target frame's label map too)
+    ld = L.ProcessWindowLoader(d, 3, H, W, 2, 7, 5, procs=2, seg_planes=(0, 1, 2), flow_planes=None)
+    (s, e, (img, flow, seg)), = list(ld)
+    assert (s, e) == (2, 7) and all(np.array_equal(flow[i], ref[2 + i][1]) and np.array_equal(seg[i], ref[2 + i][2]) for i in range(5))
+
+
+def test_process_loader_propagates_a_missing_file(dump, tmp_path):
+    import shutil
+    d, n_windows, H, W = dump, 7, 32, 64
+    d2 = str(tmp_path / "broken")
+    shutil.copytree(d, d2)
+    os.remove(L.window_paths(d2, 3, 4)[1])
+    with pytest.raises(Exception):
+        for _ in L.ProcessWindowLoader(d2, 3, H, W, 0, n_windows, 4, procs=2):
+            pass
+
+
+def test_run_sequence_with_process_loader_reports_the_time_split(dump, c_oracle):
+    """run_sequence over the process loader == over inline loads (poses bit for bit: the unread planes do not enter the
+    path), and the time split it reports adds up."""
+    from davo_amd import sequence as S, parse_version, FLAGSHIP_VERSION
+    d, n_windows, H, W = dump, 7, 32, 64
+    cfg = parse_version(FLAGSHIP_VERSION)
+    weights = synth.make_weights(cfg)
+    infer = lambda img, flow, seg: c_oracle.forward(cfg, img, flow, seg, weights)      # noqa: E731 — the checker stands in for the GPU
+    fac = S.kitti_window_loader(d, 3, n_windows + 2, H, W)
+    ref_traj, ref_poses = S.run_sequence(infer, fac, n_windows + 2, 4)
+    timing = {}
+    fac2 = S.kitti_window_loader(d, 3, n_windows + 2, H, W, procs=2)
+    traj, poses = S.run_sequence(infer, fac2, n_windows + 2, 4, timing=timing)
+    assert np.array_equal(poses, ref_poses) and np.array_equal(np.array(traj), np.array(ref_traj))
+    assert timing["windows_this_rank"] == n_windows and timing["forward_s"] > 0 and timing["load_wait_s"] >= 0
+    assert timing["gather_s"] >= 0 and timing["stitch_s"] > 0

@@ -28,14 +28,25 @@ def main():
             t2 = time.perf_counter()
             print("loader alone, %2d threads, %2d decode processes: %7.1f windows/s steady, %7.1f incl. start (%.2f s to first batch)"
                   % (workers, procs, (n - n1) / (t2 - t1), n / (t2 - t0), t1 - t0), flush=True)
+        for procs in (4, 8, 12, 14):
+            t0 = t1 = time.perf_counter()
+            n = n1 = 0
+            for s, e, _ in L.ProcessWindowLoader(d, 9, H, W, 0, N - 2, B, procs=procs, prefetch=2):
+                if n == 0:
+                    t1, n1 = time.perf_counter(), e - s
+                n += e - s
+            t2 = time.perf_counter()
+            print("process loader alone, %2d worker processes (shared batch buffers, used planes only): %7.1f windows/s steady, %7.1f "
+                  "incl. start (%.2f s to first batch)" % (procs, (n - n1) / (t2 - t1), n / (t2 - t0), t1 - t0), flush=True)
         if "--cli" in sys.argv:
             from davo_amd import run_kitti_pose
             np.savez(os.path.join(d, "w.npz"), **synth.make_weights(parse_version(FLAGSHIP_VERSION)))
             for rep in range(2):                                         # second run: page cache warm, context creation still included
                 t0 = time.perf_counter()
                 run_kitti_pose.main(["--concat_img_dir", d, "--ckpt_file", os.path.join(d, "w.npz"), "--output_dir", d,
-                                     "--test_seq", "9", "--batch_size", str(B), "--loader_threads", "4"])
-                print("CLI files -> trajectory: %.2f s for %d windows" % (time.perf_counter() - t0, N - 2), flush=True)
+                                     "--test_seq", "9", "--batch_size", str(B), "--force_comm", "--report", os.path.join(d, "report.json")])
+                print("CLI files -> trajectory: %.2f s for %d windows; report %s" % (time.perf_counter() - t0, N - 2,
+                                                                                     open(os.path.join(d, "report.json")).read()), flush=True)
 
 
 if __name__ == "__main__":          # the decode processes are spawned and re-import this module
