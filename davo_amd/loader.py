@@ -259,7 +259,9 @@ class ProcessWindowLoader:
         self.args = (dump_dir, seq, H, W)
         self.lo, self.hi, self.B = lo, hi, batch_size
         self.procs, self.prefetch = max(1, procs), max(1, prefetch)
-        self.chunk = chunk or max(1, min(8, -(-batch_size // self.procs)))
+        self.chunk = chunk or max(1, min(4, batch_size))
+        # batches being filled at once: enough windows in flight (three tasks per worker) that no worker idles at a batch's end
+        self.fill = max(2, -(-3 * self.procs * self.chunk // batch_size))
         self.pin, self.unpin, self.fp, self.sp = pin, unpin, flow_planes, seg_planes
         self._segs, self._views, self._pool, self._pinned, self._unlinked = [], [], None, [], []
 
@@ -272,8 +274,7 @@ class ProcessWindowLoader:
         from multiprocessing import shared_memory
         dump_dir, seq, H, W = self.args
         B = self.B
-        FILL = 2
-        self.nring = self.prefetch + FILL + 2
+        self.nring = self.prefetch + self.fill + 2
         sizes = (B * H * 3 * W * 3, B * 4 * H * W * 2 * 4, B * 3 * H * W * 4)
         for _ in range(self.nring):
             trio = [shared_memory.SharedMemory(create=True, size=max(n, 1)) for n in sizes]
@@ -335,7 +336,7 @@ class ProcessWindowLoader:
         self._open()
         q = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
-        FILL = 2
+        FILL = self.fill
 
         def producer():
             turn = 0
