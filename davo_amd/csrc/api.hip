@@ -407,7 +407,7 @@ void davo_destroy(davo_ctx* c) {
     }
     for (auto e : c->copy_done) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    void* misc[] = {c->d_range, c->d_pose_tiles, c->d_w1patch, c->d_w2patch, c->d_w3patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
+    void* misc[] = {c->d_range, c->d_splitk, c->d_pose_tiles, c->d_w1patch, c->d_w2patch, c->d_w3patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
     for (auto& pe : c->prof_entries)
         for (auto& ab : pe.pending) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
@@ -570,6 +570,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "patch_cnv3") c->opt_patch_cnv3 = value != 0;
     else if (k == "fold_tails") c->opt_fold_tails = value < 0 ? -1 : (value > 2 ? 1 : value);
     else if (k == "deep_ring") c->opt_deep_ring = value != 0;
+    else if (k == "split_k") c->opt_split_k = value != 0;
     else if (k == "auto_range") { int rc = judge_pending(c); if (rc) return rc; c->opt_auto_range = value != 0; }
     else if (k == "force_tile") {
         // test hook: every f16x3 layer the tile fits runs as ONE launch of that tile shape (plan.h tile ids; -1 = planner)

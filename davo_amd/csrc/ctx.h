@@ -95,6 +95,9 @@ struct davo_ctx {
     bool opt_deep_ring = true;                 // f16x3: launches of at most one workgroup per CU (batch 1..4) run on LDS rings of 3..6 slots
     bool opt_merge_cnv4 = false;               // f16x3: cnv4 as whole rounds of 256x128 tiles + 128x128 remainder tiles in one grid where the batch allows
     bool opt_share_taps = true;                // f16x3: cnv3..cnv6 stage one pixel patch per filter row for its three taps
+    bool opt_split_k = true;                   // f16x3: cnv5 / cnv6 launches of at most half a workgroup per CU split their K loop in two (forward.hip)
+    float* d_splitk = nullptr;                 // split-K partial sums [4 slots][M][2][N] float32
+    size_t splitk_floats = 0;                  // ... per slot
     float* d_pose_tiles = nullptr;             // per-tile partial sums of the fused pose head
     size_t pose_tiles_floats = 0;
     bool cnv7_valid = true;

@@ -229,6 +229,40 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
             return DAVO_OK;
         }
     }
+    // Split-K.  A launch of at most half a workgroup per CU (cnv6 at batch 1: 104 tiles of 128x128, each a serial chain of 72
+    // chunks at ~0.7 us) leaves half of the chip idle and is as long as its chain: the two halves of the input channels run
+    // as two "groups" of the same kernel (the grouped-convolution path cnv7 uses: own channel offset, weight offset and
+    // output slot; the second half starts from a zero bias) into float32 partial sums, and splitk_fixup adds the two,
+    // applies ReLU and writes the stored form.  Two partial sums instead of one chain change the float32 rounding of the
+    // layer's outputs (not their value: ~1e-7 relative), so batch sizes that split and batch sizes that do not agree to
+    // rounding, not to the bit ("split_k" 0 restores the single chain).
+    if (c->opt_split_k && !fuse_pose && (li == 4 || li == 5) && L.groups == 1 && plan.size() == 1 && p.y_mode == 1 && L.cout % 32 == 0 &&
+        L.nchunks_h % (2 * L.cpb) == 0 && ((L.nchunks_h / 2) % 3) == 0 && plan[0].tile != TILE_208x256) {
+        const TileShape ts = tile_shape(plan[0].tile);
+        const int mtiles = (p.M + ts.bm - 1) / ts.bm, ntn = L.npad_h / ts.bn;
+        if ((long)mtiles * ntn * 2 <= c->ncu) {
+            const size_t need = (size_t)p.M * 2 * L.cout;
+            if (need > c->splitk_floats) {
+                if (c->d_splitk) { int rs = sync_all_slots(c); if (rs) return rs; HIP_TRY(c, hipFree(c->d_splitk)); c->d_splitk = nullptr; }
+                HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_splitk), need * sizeof(float) * 4));   // x4: one region per in-flight slot
+                c->splitk_floats = need;
+            }
+            const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;
+            float* part = c->d_splitk + (size_t)slot_idx * c->splitk_floats;
+            ConvParamsH ps = p;
+            ps.nchunks = L.nchunks_h / 2;
+            ps.g_x_boff = (L.cin / 2) * 4; ps.g_w = (long)ps.nchunks * 128; ps.g_bias = L.npad_h; ps.g_y_coff = L.cout;
+            ps.y = reinterpret_cast<uint8_t*>(part); ps.y_mode = 0; ps.y_ld = 2 * L.cout; ps.relu = 0; ps.range = nullptr;
+            ps.ntiles_n = ntn; ps.mtile0 = 0;
+            dim3 grid(mtiles * ntn, 2);
+            ps.deep = c->opt_deep_ring ? 1 : 0;
+            c->last_plan[li][0] = ((p.M + 127) / 128) * 1000 + plan[0].tile;
+            ProfScope pscope(c, L.label);
+            HIP_TRY(c, launch_layer_h3(li, plan[0].tile, ps, grid, c->stream));
+            HIP_TRY(c, launch_splitk_fixup(part, p.M, L.cout, 2, 1, p.y, p.range, c->stream));
+            return DAVO_OK;
+        }
+    }
     for (size_t i = 0; i < plan.size() && i < 2; ++i) {
         const TileShape ts = tile_shape(plan[i].tile);
         p.ntiles_n = L.npad_h / ts.bn;

@@ -77,6 +77,13 @@ hipError_t launch_cnv3_patch(const ConvPatchParams& p, int nblk, hipStream_t s) 
     return hipGetLastError();
 }
 
+hipError_t launch_splitk_fixup(const float* d_part, long M, int N, int S, int relu, uint8_t* d_y, unsigned* d_range, hipStream_t s) {
+    if (N < 32 || N % 32 || S < 2 || M < 1) return hipErrorInvalidValue;
+    const long pairs = M * (N / 2);
+    hipLaunchKernelGGL(splitk_fixup, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, d_part, pairs, N, S, relu, d_y, d_range);
+    return hipGetLastError();
+}
+
 hipError_t launch_pose_from_tiles(const float* d_tiles, int NB, int P, int bm, int mtiles, int ntiles_n,
                                   const float* d_bpred, float* d_pose, hipStream_t s) {
     hipLaunchKernelGGL(pose_from_tiles, dim3(NB * 6), dim3(64), 0, s, d_tiles, NB, P, bm, mtiles, ntiles_n, d_bpred, d_pose);

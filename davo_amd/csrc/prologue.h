@@ -336,6 +336,40 @@ __global__ __launch_bounds__(64) void pose_from_tiles(const float* __restrict__ 
     if (threadIdx.x == 0) pose[i] = 0.01f * (tot / (float)P + bpred[hk]);
 }
 
+// Split-K fix-up (forward.hip: small batches): out[m][n] = stored(relu(part[m][0][n] + part[m][1][n] + ...)) in the f16x3
+// activation layout (per pixel, per 32 channels: 32 hi halves | 32 lo halves).  The partial sums carry the layer's
+// out_scale already; fixed order of the S terms.  One thread per channel pair; N a multiple of 32.
+__global__ __launch_bounds__(256) void splitk_fixup(const float* __restrict__ part, long total_pairs, int N, int S, int relu,
+                                                    uint8_t* __restrict__ y, unsigned* __restrict__ range) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    float vmax = 0.f;
+    if (idx < total_pairs) {
+        const int half_n = N >> 1;
+        const long m = idx / half_n;
+        const int n = (int)(idx - m * half_n) * 2;
+        const float2* src = reinterpret_cast<const float2*>(part + (m * S) * N + n);
+        float2 v = src[0];
+        for (int s = 1; s < S; ++s) {
+            const float2 t = src[(long)s * half_n];
+            v.x += t.x; v.y += t.y;
+        }
+        const float lo_clamp = relu ? 0.f : -65504.f;
+        v.x = fmaxf(v.x, lo_clamp); v.y = fmaxf(v.y, lo_clamp);
+        vmax = fmaxf(fabsf(v.x), fabsf(v.y));
+        v.x = fminf(v.x, 65504.f); v.y = fminf(v.y, 65504.f);
+        const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y;
+        const _Float16 l0 = (_Float16)(v.x - (float)h0), l1 = (_Float16)(v.y - (float)h1);
+        uint8_t* o = y + m * (long)N * 4 + (n >> 5) * 128 + (n & 31) * 2;
+        *reinterpret_cast<unsigned*>(o) = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        *reinterpret_cast<unsigned*>(o + 64) = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+    if (range) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > __atomic_load_n(range, __ATOMIC_RELAXED)) atomicMax(range, __float_as_uint(vmax));
+    }
+}
+
 // ---- on-device cross-check (impl 1): one thread per output element, reference layouts ----
 __global__ __launch_bounds__(256) void conv_direct(const float* __restrict__ x, int N, int Hin, int Win, int Cin,
                                                    int x_ld, int x_coff,

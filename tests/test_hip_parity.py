@@ -126,6 +126,8 @@ def test_batching_is_per_sample_and_deterministic(precision, fuse_pose):
     weights = synth.make_weights(cfg)
     e = _engine(cfg, 128, 416, 8, weights, precision)
     e.set_option("fuse_pose", fuse_pose)
+    if not fuse_pose:
+        e.set_option("split_k", 0)      # bit-identity across batch sizes is a property of the single K chain (split_k: to rounding)
 
     def same(a, b):
         if fuse_pose:
@@ -1199,3 +1201,30 @@ def test_config4_shape_from_files_one_rank_with_forced_gather(tmp_path, c_oracle
         assert r[k] >= 0.0
     assert r["forward_s"] > 0 and r["total_s"] >= r["forward_s"] and r["range_recovery"]["f32_batches"] == 0
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("psm_")]
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 128, 416), (2, 64, 96), (1, 256, 832), (1, 36, 100)])
+def test_split_k_small_batches(c_oracle, B, H, W):
+    """"split_k": cnv5 / cnv6 launches of at most half a workgroup per CU run the two halves of their input channels as
+    two groups into float32 partial sums, a fix-up kernel adds them (ReLU, fp16 pairs, range record).  Against the single
+    chain: the same activations to float32 rounding; against the oracle: the bar; launch after launch: the same bits."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(B, H, W)
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, H, W, B, weights, "f16x3")
+    shp = (2 * B, (H + 3) // 4, (W + 3) // 4, 256)
+    e.set_option("split_k", 0)
+    one = e.forward(img, flow, seg).copy()
+    a5, a6 = e.debug_read("cnv5", shp).copy(), e.debug_read("cnv6", shp).copy()
+    e.set_option("split_k", 1)
+    two = e.forward(img, flow, seg).copy()
+    assert_layer_close(e.debug_read("cnv5", shp), a5, "cnv5 split-K vs single chain", rtol=2e-6)
+    assert_layer_close(e.debug_read("cnv6", shp), a6, "cnv6 split-K vs single chain", rtol=2e-6)
+    assert np.abs(two - one).max() <= 2e-6 * np.abs(one).max()
+    for _ in range(3):
+        assert np.array_equal(e.forward(img, flow, seg), two)
+    mx, _ = e.activation_range()
+    assert mx["cnv5"] > 0 and mx["cnv6"] > 0                               # the fix-up kernel keeps the range record
+    if H * W <= 128 * 416:
+        assert_pose_close(two, c_oracle.forward(cfg, img, flow, seg, weights), "split-K %dx%d B=%d" % (H, W, B))
+    e.close()
