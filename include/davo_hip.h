@@ -181,11 +181,24 @@ int davo_range_stats(davo_ctx* ctx, long long* recalibrations, long long* f32_ba
  * Kernel-fusion switches of the f16x3 path (both modes give the same poses to ~1e-7):
  *   "fuse_pose" (default 1): pred 1x1 + spatial mean + 0.01 (nets/posenn.py:240-250) run in cnv7's
  *       epilogue; the cnv7 activation is never written to HBM.  0 = cnv7 stored, separate pose-head kernels.
- *   "fold_tails" (default 1): the 2->8->19 excitation MLP runs in the workgroup of the squeeze launch that delivers a
- *       triplet's last partial sum, and the pose head's sum over cnv7's tiles in the workgroup of the cnv7 launch that
- *       finishes last (csrc/pose_tail.h: ticket counters, agent-scope fences, fixed summation order): two launches fewer
- *       per batch.  0 = se_excite / pose_from_tiles as launches of their own.  Bit-identical results.
- *   "fuse_pack" (default 0): cnv1 builds its input patch from the raw inputs (mask + pack fused in).
+ *   "fold_tails" (default -1 = auto): 1 = the 2->8->19 excitation MLP runs in the workgroup of the squeeze launch that
+ *       delivers a triplet's last partial sum, and the pose head's sum over cnv7's tiles in the workgroup of the cnv7
+ *       launch that finishes last (csrc/pose_tail.h: ticket counters, agent-scope loads and stores, fixed summation order):
+ *       two launches fewer per batch; 2 = the excitation only; 0 = se_excite / pose_from_tiles as launches of their own.
+ *       The memory-side round trips cost more than the launches they save except at the smallest batches (B = 32: squeeze
+ *       +18 us, cnv7 +3 us against 13 us of launches), so auto folds the excitation at batch <= 2 only.  Bit-identical.
+ *   "deep_ring" (default 1): launches of at most one workgroup per CU (batch 1..4) run the same tiles on LDS rings of 3..6
+ *       slots instead of 2 (more chunks of LDS-DMA in flight behind a counted wait).  Bit-identical results.
+ *   "split_k" (default 1): cnv5 / cnv6 launches of at most half a workgroup per CU (batch 1 at 128x416) run the two halves
+ *       of their input channels as two groups of the same kernel into float32 partial sums; a fix-up kernel adds them,
+ *       applies ReLU and writes the stored form (cnv6 at batch 1: 52 -> 39 us).  Two partial sums instead of one chain: the
+ *       layer's outputs - and so the poses - agree with the single chain to float32 rounding (~1e-7 relative), not to the
+ *       bit; 0 = one K chain at every batch size (poses then do not depend on how windows are batched, with "fuse_pose" 0
+ *       to the bit).
+ *   "merge_cnv4" (default 0): cnv4 as whole rounds of 256x128 tiles + 128x128 remainder tiles in one grid like cnv5 / cnv6
+ *       ("merge_rem"); measured level with the single launch of 128x128 tiles.  Bit-identical results.
+ *   "fuse_pack" (default -1 = auto, which is off: measured level at every batch): 1 = cnv1 builds its input patch from
+ *       the raw inputs (mask + pack fused in).
  *   "patch_cnv2", "patch_cnv3" (default 1): cnv2 (5x5 stride 2) / cnv3 (3x3 dilation 2) read their taps from an LDS-staged
  *       input patch (csrc/conv_patch_h3.h); 0 = the implicit-GEMM kernel.  The two sum a pixel's taps in different orders:
  *       poses agree to float32 rounding.

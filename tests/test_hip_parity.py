@@ -280,6 +280,13 @@ def test_host_entry_chunked_copy_and_pinned_buffers():
     img, flow, seg = synth.make_inputs(B, 64, 96)
     e = _engine(cfg, 64, 96, B, synth.make_weights(cfg), "f16x3")
     e.set_option("host_chunk", 0)
+    whole = e.forward(img, flow, seg).copy()
+    e.set_option("host_chunk", 8)
+    # default plan: a sub-batch of 8 is small enough for split-K (two partial sums per cnv5 / cnv6 output), the whole batch
+    # is not: the same poses to float32 rounding, like the fused pose head's tile sums
+    assert np.abs(e.forward(img, flow, seg) - whole).max() <= 1e-6 * np.abs(whole).max()
+    e.set_option("split_k", 0)                                # one K chain whatever the batch: bit-identical
+    e.set_option("host_chunk", 0)
     want = e.forward(img, flow, seg).copy()
     e.set_option("host_chunk", 8)
     assert np.array_equal(e.forward(img, flow, seg), want)
@@ -739,6 +746,7 @@ def test_tile_208x256_forced(c_oracle, B, H, W):
     weights = synth.make_weights(cfg)
     want = c_oracle.forward(cfg, img, flow, seg, weights)
     e = _engine(cfg, H, W, B, weights, "f16x3")
+    e.set_option("split_k", 0)                               # tile-independent bits are a property of the single K chain
     h2, w2 = -(-H // 4), -(-W // 4)
     for fuse_pose in (0, 1):
         e.set_option("fuse_pose", fuse_pose)
