@@ -235,13 +235,19 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
     // output slot; the second half starts from a zero bias) into float32 partial sums, and splitk_fixup adds the two,
     // applies ReLU and writes the stored form.  Two partial sums instead of one chain change the float32 rounding of the
     // layer's outputs (not their value: ~1e-7 relative), so batch sizes that split and batch sizes that do not agree to
-    // rounding, not to the bit ("split_k" 0 restores the single chain).
+    // rounding, not to the bit ("split_k" 0 restores the single chain).  (With S parts: S groups, S partial sums.)
     if (c->opt_split_k && !fuse_pose && (li == 4 || li == 5) && L.groups == 1 && plan.size() == 1 && p.y_mode == 1 && L.cout % 32 == 0 &&
-        L.nchunks_h % (2 * L.cpb) == 0 && ((L.nchunks_h / 2) % 3) == 0 && plan[0].tile != TILE_208x256) {
+        plan[0].tile != TILE_208x256) {
         const TileShape ts = tile_shape(plan[0].tile);
         const int mtiles = (p.M + ts.bm - 1) / ts.bm, ntn = L.npad_h / ts.bn;
-        if ((long)mtiles * ntn * 2 <= c->ncu) {
-            const size_t need = (size_t)p.M * 2 * L.cout;
+        const long tiles = (long)mtiles * ntn;
+        // parts: whole channel blocks each, whole filter rows (shared-tap staging walks a row's three taps together).  Four parts
+        // where the workgroups then still fit side by side (two per CU on the two-slot ring), else two (one per CU, deep ring)
+        auto fits = [&](int S) { return L.nchunks_h % (S * L.cpb) == 0 && ((L.nchunks_h / S) % 3) == 0; };
+        const int per_cu = ts.lds * 2 <= 160 * 1024 ? 2 : 1;
+        const int S = (fits(4) && tiles * 4 <= (long)per_cu * c->ncu && tiles * 2 <= c->ncu) ? 4 : (fits(2) && tiles * 2 <= c->ncu ? 2 : 1);       // two parts at two per CU (B = 2) measured slower: 54 -> 57 us
+        if (S > 1) {
+            const size_t need = (size_t)p.M * S * L.cout;
             if (need > c->splitk_floats) {
                 if (c->d_splitk) { int rs = sync_all_slots(c); if (rs) return rs; HIP_TRY(c, hipFree(c->d_splitk)); c->d_splitk = nullptr; }
                 HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_splitk), need * sizeof(float) * 4));   // x4: one region per in-flight slot
@@ -250,16 +256,16 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
             const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;
             float* part = c->d_splitk + (size_t)slot_idx * c->splitk_floats;
             ConvParamsH ps = p;
-            ps.nchunks = L.nchunks_h / 2;
-            ps.g_x_boff = (L.cin / 2) * 4; ps.g_w = (long)ps.nchunks * 128; ps.g_bias = L.npad_h; ps.g_y_coff = L.cout;
-            ps.y = reinterpret_cast<uint8_t*>(part); ps.y_mode = 0; ps.y_ld = 2 * L.cout; ps.relu = 0; ps.range = nullptr;
+            ps.nchunks = L.nchunks_h / S;
+            ps.g_x_boff = (L.cin / S) * 4; ps.g_w = (long)ps.nchunks * 128; ps.g_bias = L.npad_h; ps.g_y_coff = L.cout;
+            ps.y = reinterpret_cast<uint8_t*>(part); ps.y_mode = 0; ps.y_ld = S * L.cout; ps.relu = 0; ps.range = nullptr;
             ps.ntiles_n = ntn; ps.mtile0 = 0;
-            dim3 grid(mtiles * ntn, 2);
-            ps.deep = c->opt_deep_ring ? 1 : 0;
+            dim3 grid(mtiles * ntn, S);
+            ps.deep = c->opt_deep_ring && tiles * S <= c->ncu;
             c->last_plan[li][0] = ((p.M + 127) / 128) * 1000 + plan[0].tile;
             ProfScope pscope(c, L.label);
             HIP_TRY(c, launch_layer_h3(li, plan[0].tile, ps, grid, c->stream));
-            HIP_TRY(c, launch_splitk_fixup(part, p.M, L.cout, 2, 1, p.y, p.range, c->stream));
+            HIP_TRY(c, launch_splitk_fixup(part, p.M, L.cout, S, 1, p.y, p.range, c->stream));
             return DAVO_OK;
         }
     }

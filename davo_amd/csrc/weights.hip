@@ -232,8 +232,8 @@ int build_packed_weights_h3(davo_ctx* c) {
         ConvLayer& L = c->L[li];
         const size_t per_group = (size_t)L.npad_h * L.nchunks_h * 64;
         std::vector<_Float16> wp(per_group * L.groups, (_Float16)0.0f);
-        // a single-group layer's bias is followed by npad_h zeros: the second half of a split-K launch (forward.hip) starts from them
-        std::vector<float> bp((size_t)L.npad_h * (L.groups > 2 ? L.groups : 2), 0.f);
+        // a single-group layer's bias is followed by 3 x npad_h zeros: the later parts of a split-K launch (forward.hip) start from them
+        std::vector<float> bp((size_t)L.npad_h * (L.groups > 1 ? L.groups : 4), 0.f);
         {   // one power-of-two scale per layer (both heads share the launch)
             float sc = 1e30f;
             if (li < 5) {
