@@ -105,6 +105,8 @@ struct davo_ctx {
     int impl = 0;
     int precision = 1;                         // 0 = FP32 MFMA (bit-exact fmaf chains), 1 = f16x3 split (default)
     bool packed_h_ready = false;
+    int weight_channel_spread_log2 = 0;        // largest log2 spread of the per-input-channel weight norms over cnv2..cnv7 (weights.hip)
+    std::string weight_channel_spread_layer;   // ... and the tensor that has it
     int last_precision = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;

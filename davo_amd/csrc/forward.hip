@@ -108,6 +108,7 @@ int check_range(davo_ctx* c, const unsigned raw[6]) {
 
 namespace {
 
+constexpr int MAX_WEIGHT_CHANNEL_SPREAD_LOG2 = 14;     // f16x3 per-channel guard (weights.hip)
 constexpr int FOLD_EXCITE_MAX_BATCH = 2;       // auto modes: largest batch that folds the excitation / fuses mask + pack into cnv1
 constexpr int FUSE_PACK_MAX_BATCH = 0;        // measured level at every batch (cnv1 +5 us for mask_pack's 6.7): nowhere by default
 
@@ -381,8 +382,18 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     }
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->packed_ready) { int rc = build_packed_weights(c); if (rc) return rc; }
-    const bool h3 = c->impl == 0 && c->precision == 1;
+    bool h3 = c->impl == 0 && c->precision == 1;
     if (h3 && !c->packed_h_ready) { int rc = build_packed_weights_h3(c); if (rc) return rc; }
+    if (h3 && c->weight_channel_spread_log2 > MAX_WEIGHT_CHANNEL_SPREAD_LOG2) {
+        // a consumer's per-input-channel weight norms span more than 2^14: per-layer storage scales cannot keep every channel's fp16
+        // pair float32-grade (weights.hip).  The reference's float32 graph has no such limit (nets/posenn.py:205-215): float32 kernels.
+        if (!c->opt_auto_range)
+            return fail(c, DAVO_ERR_RANGE, "`%s': per-input-channel weight norms span 2^%d (> 2^%d): the f16x3 storage cannot hold every channel "
+                        "float32-grade - davo_set_precision(ctx, 0), or leave \"auto_range\" on", c->weight_channel_spread_layer.c_str(),
+                        c->weight_channel_spread_log2, MAX_WEIGHT_CHANNEL_SPREAD_LOG2);
+        h3 = false;
+        ++c->n_f32_batches;
+    }
 
     const int H = c->H, W = c->W, HW = H * W, NB = 2 * B;
     const Variant& v = c->v;

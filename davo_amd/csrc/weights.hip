@@ -330,6 +330,36 @@ int build_packed_weights_h3(davo_ctx* c) {
         int rc = upload_bytes(c, wp.data(), wp.size() * sizeof(_Float16), reinterpret_cast<void**>(&c->d_w3patch));
         if (rc) return rc;
     }
+    {   // Per-channel guard of the f16x3 arithmetic.  One power-of-two scale per layer keeps the LAYER's largest
+        // activation at [512, 1024); a channel whose activations are 2^-r of that keeps its hi half but loses its lo half below
+        // r ~ 12 (absolute error 2^-25 of the stored value), which only matters if the consuming layer multiplies that
+        // channel by weights 2^r larger than the others' - visible here, in the weights: the spread of the per-input-channel
+        // weight norms of cnv2..cnv7.  Measured (tools/exp_dynamic_range.py): r = 14 -> 2.6e-6, r = 18 -> 5e-5, r = 22 -> 9e-4
+        // against the 1e-4 bar.  Beyond 2^14 the network runs on the float32 kernels (auto_range) or is refused (DAVO_ERR_RANGE).
+        c->weight_channel_spread_log2 = 0;
+        c->weight_channel_spread_layer.clear();
+        const char* lw[6] = {"pose_exp_net/cnv2/weights", "pose_exp_net/cnv3/weights", "pose_exp_net/cnv4/weights", "pose_exp_net/cnv5/weights",
+                             "/cnv6/weights", "/cnv7/weights"};
+        for (int k = 0; k < 6; ++k) {
+            for (int h = 0; h < (k < 4 ? 1 : 2); ++h) {
+                const std::string name = k < 4 ? std::string(lw[k]) : std::string("pose_exp_net/pose/") + heads[h] + lw[k];
+                const HostTensor& t = W(name);
+                const int64_t taps = t.shape[0] * t.shape[1], cin = t.shape[2], cout = t.shape[3];
+                float mx = 0.f, mn = 3.4e38f;
+                for (int64_t ci = 0; ci < cin; ++ci) {
+                    float m = 0.f;
+                    for (int64_t tp = 0; tp < taps; ++tp)
+                        for (int64_t co = 0; co < cout; ++co) m = std::fmax(m, std::fabs(t.data[(tp * cin + ci) * cout + co]));
+                    if (m > 0.f && std::isfinite(m)) { mx = std::fmax(mx, m); mn = std::fmin(mn, m); }
+                }
+                if (mx > 0.f && mn > 0.f) {
+                    int e1, e0;
+                    (void)frexpf(mx, &e1); (void)frexpf(mn, &e0);
+                    if (e1 - e0 > c->weight_channel_spread_log2) { c->weight_channel_spread_log2 = e1 - e0; c->weight_channel_spread_layer = name; }
+                }
+            }
+        }
+    }
     c->packed_h_ready = true;
     return DAVO_OK;
 }

@@ -1236,3 +1236,31 @@ def test_split_k_small_batches(c_oracle, B, H, W):
     if H * W <= 128 * 416:
         assert_pose_close(two, c_oracle.forward(cfg, img, flow, seg, weights), "split-K %dx%d B=%d" % (H, W, B))
     e.close()
+
+
+def test_per_channel_spread_beyond_the_pair_format_runs_in_float32(c_oracle):
+    """Half of cnv3's and cnv5's channels at 2^-22 of their neighbours (consumer weights x 2^22): per-layer storage scales
+    cannot keep those channels' fp16 pairs float32-grade (measured 9e-4 against the 1e-4 bar).  The spread shows in the
+    consumer's per-input-channel weight norms, so the library sees it when the weights are packed and runs this network
+    on its float32 kernels — the caller gets the reference's result, as with any float32 network (davo.py:1553-1569);
+    with auto_range off it refuses instead."""
+    from davo_amd import DavoRangeError
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(2, 64, 96)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    w2 = _scale_channels(weights, "cnv3", ["cnv4"], np.arange(0, 64, 2), -22)
+    w2 = _scale_channels(w2, "cnv5", ["pose/rotation/cnv6", "pose/translation/cnv6"], np.arange(1, 256, 2), -22)
+    e = _engine(cfg, 64, 96, 2, w2, "f16x3")
+    assert_pose_close(e.forward(img, flow, seg), want, "per-channel 2^-22 (float32 kernels)")
+    assert e.range_stats()["f32_batches"] >= 1
+    e.set_option("auto_range", 0)
+    with pytest.raises(DavoRangeError, match="per-input-channel weight norms"):
+        e.forward(img, flow, seg)
+    e.close()
+    # 2^-12 stays on the f16x3 kernels and inside the bar
+    w3 = _scale_channels(weights, "cnv3", ["cnv4"], np.arange(0, 64, 2), -12)
+    e = _engine(cfg, 64, 96, 2, w3, "f16x3")
+    assert_pose_close(e.forward(img, flow, seg), want, "per-channel 2^-12 (f16x3)")
+    assert e.range_stats()["f32_batches"] == 0
+    e.close()
