@@ -211,7 +211,10 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
     {                                                                                              \
         if constexpr ((KX_) == 1) { H3_RD(arr_[I_], base_, (I_) * 16 * 128); }                     \
         else {                                                                                     \
-            const unsigned ad_ = (xkeep >> (((KX_) == 0 ? 0 : 8) + (I_))) & 1u ? (base_) + (I_) * 16 * 128 : xzero; \
+            /* the zero row is read at the 16-byte unit the patch row would have been read at: the lanes of a service group \
+               then cover the banks once, whichever of them read zeros (all at unit 0 they collided with the patch lanes:     \
+               1.27 M conflict cycles per cnv6 launch) */                                                                     \
+            const unsigned ad_ = (xkeep >> (((KX_) == 0 ? 0 : 8) + (I_))) & 1u ? (base_) + (I_) * 16 * 128 : (xzero | ((base_) & 112u)); \
             H3_RD(arr_[I_], ad_, 0);                                                               \
         }                                                                                          \
     }
