@@ -73,6 +73,39 @@ def world_from_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def publish_id(path, ident):
+    """rank 0: the 128 id bytes appear at `path` all at once (exclusive create of a temporary, then rename)"""
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    for stale in (tmp, path):                       # a file of this very name can only be a leftover of this launcher's
+        try:
+            os.remove(stale)
+        except OSError:
+            pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    with os.fdopen(fd, "wb") as f:
+        f.write(ident)
+    os.replace(tmp, path)                           # readers see all 128 bytes or no file
+
+
+def wait_for_id(path, rank, timeout=180.0, not_before=None):
+    """ranks > 0: the id rank 0 published under THIS launcher (own uid, complete, not older than the launcher process)"""
+    t0 = time.time()
+    not_before = _launcher_start_time() if not_before is None else not_before
+    while True:
+        try:
+            st = os.stat(path)
+            if st.st_size == _lib.COMM_ID_BYTES and st.st_uid == os.getuid() and st.st_mtime >= not_before:
+                with open(path, "rb") as f:
+                    raw = f.read()
+                if len(raw) == _lib.COMM_ID_BYTES:
+                    return raw
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise CommError("rank %d: no RCCL id at %s after %.0f s (rank 0 did not start?)" % (rank, path, timeout))
+        time.sleep(0.02)
+
+
 class RcclComm:
     """``ncclCommInitRank`` on the engine's GPU.  Collective: every rank constructs it."""
 
@@ -88,34 +121,10 @@ class RcclComm:
             rc = self._L.davo_comm_unique_id(ident, err, 512)
             if rc != 0:
                 raise CommError("davo_comm_unique_id: %s" % err.value.decode())
-            tmp = "%s.%d.tmp" % (path, os.getpid())
-            for stale in (tmp, path):                   # a file of this very name can only be a leftover of this launcher's
-                try:
-                    os.remove(stale)
-                except OSError:
-                    pass
-            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
-            with os.fdopen(fd, "wb") as f:
-                f.write(bytes(ident))
-            os.replace(tmp, path)                       # readers see all 128 bytes or no file
+            publish_id(path, bytes(ident))
         else:
-            t0 = time.time()
-            not_before = _launcher_start_time()
-            while True:
-                try:
-                    st = os.stat(path)
-                    # the reader's own file (uid), complete, and written under THIS launcher
-                    if st.st_size == _lib.COMM_ID_BYTES and st.st_uid == os.getuid() and st.st_mtime >= not_before:
-                        with open(path, "rb") as f:
-                            raw = f.read()
-                        if len(raw) == _lib.COMM_ID_BYTES:
-                            ctypes.memmove(ident, raw, len(raw))
-                            break
-                except OSError:
-                    pass
-                if time.time() - t0 > timeout:
-                    raise CommError("rank %d: no RCCL id at %s after %.0f s (rank 0 did not start?)" % (self.rank, path, timeout))
-                time.sleep(0.02)
+            raw = wait_for_id(path, self.rank, timeout)
+            ctypes.memmove(ident, raw, len(raw))
         engine._check(self._L.davo_comm_init(engine._ctx, self.world, self.rank, ident))
         self._open = True
         if self.rank == 0:                              # every rank has read the id once the collective init returned

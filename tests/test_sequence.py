@@ -229,6 +229,53 @@ def test_comm_rendezvous_path_prefers_the_launcher_directory(monkeypatch, tmp_pa
     assert comm.rendezvous_path() == "/x/y"
 
 
+_RDV_CHILD = """
+import os, sys, time
+sys.path.insert(0, %r)
+from davo_amd import comm
+rank = int(os.environ["RANK"])
+path = comm.rendezvous_path()
+if rank == 0:
+    time.sleep(0.3)                                   # the readers are already polling
+    comm.publish_id(path, bytes(range(128)))
+    got = bytes(range(128))
+else:
+    got = comm.wait_for_id(path, rank, timeout=20.0)
+open(os.path.join(sys.argv[1], "id%%d" %% rank), "wb").write(got)
+"""
+
+
+def test_rendezvous_between_real_rank_processes_under_both_launchers(tmp_path):
+    """The id exchange of RcclComm (publish_id / wait_for_id) between three real processes: started by spawn_ranks (private
+    directory + nonce) and started the way torch.distributed.run starts workers (no DAVO_COMM_*: the per-user directory,
+    the name from the launcher's pid, MASTER_PORT and the elastic run id).  A stale file of the torchrun name from before
+    the launcher must not be read: the readers get rank 0's bytes, not the decoy's."""
+    import subprocess
+    import sys
+    from davo_amd import comm
+    from davo_amd.launch import spawn_ranks
+    script = tmp_path / "rdv.py"
+    script.write_text(_RDV_CHILD % os.path.dirname(HERE))
+    a = tmp_path / "a"
+    a.mkdir()
+    assert spawn_ranks([str(script), str(a)], 3, timeout=60) == 0
+    assert all(open(a / ("id%d" % r), "rb").read() == bytes(range(128)) for r in range(3))
+    # torchrun-style: this test process is the "launcher" (the ranks' parent); plant a stale decoy under the very name
+    b = tmp_path / "b"
+    b.mkdir()
+    env = dict(os.environ, MASTER_PORT="29733", TORCHELASTIC_RUN_ID="t1", TORCHELASTIC_RESTART_COUNT="0", WORLD_SIZE="3")
+    env.pop("DAVO_COMM_DIR", None); env.pop("DAVO_COMM_FILE", None); env.pop("DAVO_COMM_NONCE", None)
+    name = os.path.join(comm._private_dir(), "rccl_%d_29733_t1_0.id" % os.getpid())
+    with open(name, "wb") as f:
+        f.write(b"\xff" * 128)
+    old = comm._launcher_start_time() - 3600                    # "written an hour before this launcher started"
+    os.utime(name, (old, old))
+    procs = [subprocess.Popen([sys.executable, str(script), str(b)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in (1, 2, 0)]
+    assert [p.wait(timeout=60) for p in procs] == [0, 0, 0]
+    assert all(open(b / ("id%d" % r), "rb").read() == bytes(range(128)) for r in range(3))
+    os.remove(name)
+
+
 def test_comm_id_file_from_before_the_launcher_is_stale(tmp_path):
     """A reader accepts an id file only if it was written under its own launcher: the test for it is the launcher
     process's start time (this test's parent), so a file dated before that is never read."""
