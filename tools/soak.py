@@ -23,8 +23,11 @@ def main():
     cfg = parse_version(FLAGSHIP_VERSION)
     weights = synth.make_weights(cfg)
     bad = 0
+    # round 3: the small batches too (deep LDS rings, split-K + fix-up kernel, 128x32 tiles with the fused pose head)
     for B, H, W, nsets, precision in ((32, 128, 416, 3, "f16x3"), (16, 128, 416, 3, "f16x3"), (5, 128, 416, 2, "f16x3"),
-                                      (8, 256, 832, 2, "f16x3"), (7, 52, 172, 3, "f16x3"), (32, 128, 416, 2, "f32")):
+                                      (8, 256, 832, 2, "f16x3"), (7, 52, 172, 3, "f16x3"), (32, 128, 416, 2, "f32"),
+                                      (1, 128, 416, 3, "f16x3"), (2, 128, 416, 3, "f16x3"), (3, 128, 416, 3, "f16x3"),
+                                      (4, 128, 416, 2, "f16x3"), (1, 256, 832, 2, "f16x3"), (3, 52, 172, 3, "f16x3")):
         e = Engine(cfg, H, W, B)
         e.load_weights(weights)
         e.set_precision(precision)
