@@ -264,6 +264,7 @@ class ProcessWindowLoader:
         self.fill = max(2, -(-3 * self.procs * self.chunk // batch_size))
         self.pin, self.unpin, self.fp, self.sp = pin, unpin, flow_planes, seg_planes
         self._segs, self._views, self._pool, self._pinned, self._unlinked = [], [], None, [], []
+        self._thread = self._q = self._stop_evt = None
 
     def __len__(self):
         return -(-(self.hi - self.lo) // self.B)
@@ -306,9 +307,23 @@ class ProcessWindowLoader:
                     except OSError:
                         pass
 
+    def _halt(self):
+        """a loader that was started but never (or not fully) iterated: stop its producer before the buffers go away"""
+        t = self._thread
+        if t is not None:
+            self._stop_evt.set()
+            while t.is_alive():
+                try:
+                    self._q.get_nowait()
+                except queue.Empty:
+                    pass
+                t.join(timeout=0.05)
+            self._thread = None
+
     def close(self):
         """unpin and unmap the batch buffers: every array this loader has yielded is invalid afterwards (numpy does not keep
         a shared-memory mapping alive).  Called by __del__; iteration itself only stops the workers (_stop)."""
+        self._halt()
         self._stop()
         if self.unpin is not None:
             for v in self._pinned:
@@ -332,11 +347,15 @@ class ProcessWindowLoader:
         except Exception:                                 # noqa: BLE001 — interpreter teardown
             pass
 
-    def __iter__(self):
+    def start(self):
+        """Create the buffers, start the workers and begin filling batches now (idempotent).  The workers need ~0.5 s to come up
+        (spawn + imports): a caller that starts the loader before it builds its GPU context hides that behind the set-up."""
+        if self._thread is not None:
+            return self
         self._open()
-        q = queue.Queue(maxsize=self.prefetch)
-        stop = threading.Event()
-        FILL = self.fill
+        self._q = queue.Queue(maxsize=self.prefetch)
+        self._stop_evt = threading.Event()
+        q, stop, FILL = self._q, self._stop_evt, self.fill
 
         def producer():
             turn = 0
@@ -367,8 +386,13 @@ class ProcessWindowLoader:
                 return
             q.put(None)
 
-        t = threading.Thread(target=producer, daemon=True)
-        t.start()
+        self._thread = threading.Thread(target=producer, daemon=True)
+        self._thread.start()
+        return self
+
+    def __iter__(self):
+        self.start()
+        q, stop, t = self._q, self._stop_evt, self._thread
         try:
             while True:
                 item = q.get()
@@ -386,6 +410,7 @@ class ProcessWindowLoader:
                 except queue.Empty:
                     pass
                 t.join(timeout=0.05)
+            self._thread = None
             self._stop()
 
 

@@ -93,6 +93,8 @@ def main(argv=None):
                                      workers=a.loader_threads, decode_procs=a.decode_procs, procs=procs,
                                      pin=lambda arr: pin_array(arr, device_index), unpin=unpin_array,
                                      seg_planes=(0, 1, 2) if static_all else None)
+        # the loader's workers come up (spawn + imports: ~0.5 s) while the checkpoint is read and the GPU context is built
+        load.prestart(*S.shard_windows(n_frames - 2, world, rank), a.batch_size)
         from .tf_checkpoint import load_weights
         weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
 

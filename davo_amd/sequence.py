@@ -209,8 +209,18 @@ class kitti_window_loader:
         self.workers, self.prefetch, self.alloc, self.decode_procs = workers, prefetch, alloc, decode_procs
         self.procs, self.pin, self.unpin, self.seg_planes = procs, pin, unpin, seg_planes
 
+    def prestart(self, lo, hi, batch_size):
+        """Build this rank's process loader now and let it start filling batches: its workers need ~0.5 s to come up, which
+        then passes behind the caller's GPU set-up instead of in front of the first batch.  for_range hands it out."""
+        if self.procs > 0:
+            self._early = ((lo, hi, batch_size), self.for_range(lo, hi, batch_size).start())
+
     def for_range(self, lo, hi, batch_size):
         from . import loader as L
+        early = getattr(self, "_early", None)
+        if early is not None and early[0] == (lo, hi, batch_size):
+            self._early = None
+            return early[1]
         if self.procs > 0:      # worker processes fill shared (page-locked) batch buffers: davo_amd/loader.py, ProcessWindowLoader
             return L.ProcessWindowLoader(self.dir, self.seq, self.H, self.W, lo, hi, batch_size, self.procs, self.prefetch,
                                          pin=self.pin, unpin=self.unpin,

@@ -162,3 +162,22 @@ def test_run_sequence_with_process_loader_reports_the_time_split(dump, c_oracle)
     assert np.array_equal(poses, ref_poses) and np.array_equal(np.array(traj), np.array(ref_traj))
     assert timing["windows_this_rank"] == n_windows and timing["forward_s"] > 0 and timing["load_wait_s"] >= 0
     assert timing["gather_s"] >= 0 and timing["stitch_s"] > 0
+
+
+def test_process_loader_started_early_and_never_iterated_cleans_up(dump):
+    """start() fills batches ahead of the first next(); a loader that is started and then dropped (or closed) stops its
+    producer and leaves nothing in /dev/shm."""
+    d, n_windows, H, W = dump, 7, 32, 64
+    ld = L.ProcessWindowLoader(d, 3, H, W, 0, n_windows, 4, procs=2).start()
+    names = [sm.name.lstrip("/") for trio in ld._segs for sm in trio]
+    assert names and ld.start() is ld                                     # idempotent
+    got = [(s, e) for s, e, _ in ld]
+    assert got == [(0, 4), (4, 7)]
+    ld.close()
+    ld2 = L.ProcessWindowLoader(d, 3, H, W, 0, n_windows, 4, procs=2).start()
+    names += [sm.name.lstrip("/") for trio in ld2._segs for sm in trio]
+    ld2.close()                                                           # never iterated
+    assert not any(os.path.exists("/dev/shm/" + n) for n in names)
+    fac = S.kitti_window_loader(d, 3, n_windows + 2, H, W, procs=2)
+    fac.prestart(0, n_windows, 4)
+    assert [(s, e) for s, e, _ in fac.for_range(0, n_windows, 4)] == [(0, 4), (4, 7)]
