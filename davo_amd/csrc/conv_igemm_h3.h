@@ -755,6 +755,14 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
             coff[jj] = (unsigned)((ng >> ocb_log2) * (ocb * 4) + (ng & (ocb - 1)) * 2 + (odd ? ocb * 2 - 2 : 0));
         }
         constexpr int CW = M16 ? 16 : 32;                      // channels per column group
+/* experiment (-DDAVO_STORE_SC1): write-through stores (agent scope, global_store_dword ... sc1) leave no dirty lines for the
+   end-of-kernel release to write back - measured 7 % slower end to end (cnv4 +23 us, cnv5 +37, cnv6 +25 at B = 32:
+   profiles/r03_writethrough_stores_ab.log): the L2 merges the 64-byte pieces of a row that write-through sends out one by one */
+#ifdef DAVO_STORE_SC1
+#define H3_STORE_U32(ptr_, val_) __hip_atomic_store(reinterpret_cast<unsigned*>(ptr_), (val_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define H3_STORE_U32(ptr_, val_) (*reinterpret_cast<unsigned*>(ptr_) = (val_))
+#endif
 #define H3_STORE_ROWS(COFF_)                                                                        \
         _Pragma("unroll") for (int ii = 0; ii < NRG; ++ii)                                          \
             _Pragma("unroll") for (int r = 0; r < NREG; ++r) {                                      \
@@ -768,12 +776,13 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
                     const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) |           \
                                        ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);    \
                     const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   /* quad_perm [1,0,3,2] */ \
-                    *reinterpret_cast<unsigned*>(rowp + (COFF_)) = __builtin_amdgcn_perm(xn, x, sel); \
+                    H3_STORE_U32(rowp + (COFF_), __builtin_amdgcn_perm(xn, x, sel));                   \
                 }                                                                                   \
             }
         if (regular) { H3_STORE_ROWS((jj * CW >> 5) * 128 + ((jj * CW) & 31) * 2) }
         else { H3_STORE_ROWS(coff[jj] - coff0) }
 #undef H3_STORE_ROWS
+#undef H3_STORE_U32
     } else {
 #pragma unroll
     for (int jj = 0; jj < NCG; ++jj) {
