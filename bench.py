@@ -117,6 +117,7 @@ def parse_args():
     ap.add_argument("--no-f32", action="store_true", help="skip the strict-float32 leg (roofline.reference_arithmetic)")
     ap.add_argument("--profile-stride", type=int, default=0,
                     help="HIP events around the dominant kernel of every n-th timed step (default: 4 when steps >= 40, else 1)")
+    ap.add_argument("--options", default="", help="davo_set_option pairs applied before the first step, k=v,k=v (A/B of launch plans under the profiler)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="triplets per CPU-baseline pass")
     return ap.parse_args()
@@ -145,6 +146,9 @@ def main():
     eng = Engine(cfg, H, W, B, device=device_index)  # raises without a GPU: the HIP path has no CPU fallback
     eng.load_weights(weights)
     eng.set_precision(args.precision)
+    for kv in filter(None, args.options.split(",")):
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     # raises on any RCCL failure: no gloo, no TCP stand-in
     comm = RcclComm(eng, rank, world) if (world > 1 or args.force_comm) else None
 
@@ -371,7 +375,8 @@ def main():
             "data": "synthetic (splitmix64 seed 8964; random-init He-uniform weights; no KITTI/ckpt offline)",
             "config": {"workload": workload_name(B, H, W, world),
                        "version": FLAGSHIP_VERSION, "batch_per_gpu": B, "height": H, "width": W,
-                       "parallelism": "window-sharded replicas x%d" % world, "batches_in_flight": nset},
+                       "parallelism": "window-sharded replicas x%d" % world, "batches_in_flight": nset,
+                       **({"options": args.options} if args.options else {})},
             "roofline": roof,
             "timing": timing,
             "whole_path_tflops_per_gpu": round(whole, 2),

@@ -849,12 +849,21 @@ void conv_igemm_h3(ConvParamsH p) {
 // tiles, then the second half of the remainder.  Ordinals keep id % 8, so xcd_remap still gives each XCD a contiguous run
 // of each kind.
 // TNM: N extent of the main tile in 64-column units per wave pair: 4 = 256x256 (cnv5, cnv6), 2 = 256x128 (cnv4, 128 output channels).
+// order 1 (round 3): the offset is taken per XCD instead of inside every XCD - the even XCDs run all their short tiles first, the
+// odd XCDs all theirs last (x = id % 8 is the XCD, i = id / 8 its i-th workgroup in dispatch order).  The store bursts of the two
+// halves of the chip still do not coincide (HBM is shared), but the CUs of one XCD stay in step on neighbouring tiles, so the
+// halo rows one tile fetched are still in that XCD's L2 when its neighbour reads them.
 template <int LAYER, int RATE, int TNM = 4>
-__global__ __launch_bounds__(512, 2) void conv_igemm_h3_mainrem(ConvParamsH pm, ConvParamsH pr, int n_main, int n_rem) {
+__global__ __launch_bounds__(512, 2) void conv_igemm_h3_mainrem(ConvParamsH pm, ConvParamsH pr, int n_main, int n_rem, int order) {
     const int b = blockIdx.x, h = n_rem >> 1;
     int ord;
     bool rem;
-    if (b < 2 * h) { rem = ((b >> 5) & 1) == 0; ord = ((b >> 6) << 5) | (b & 31); }
+    if (order == 1) {
+        const int x = b & 7, i = b >> 3, ns = n_rem >> 3, nl = n_main >> 3;       // per XCD: ns short, nl long tiles
+        if (x & 1) { rem = i >= nl; ord = ((rem ? i - nl : i) << 3) | x; }
+        else { rem = i < ns; ord = ((rem ? i : i - ns) << 3) | x; }
+    }
+    else if (b < 2 * h) { rem = ((b >> 5) & 1) == 0; ord = ((b >> 6) << 5) | (b & 31); }
     else if (b < h + n_main) { rem = false; ord = b - h; }
     else { rem = true; ord = b - n_main; }
     if (rem) conv_igemm_h3_body<3, 1, 4, 2, 1, 2, LAYER, true, false, true, 3, 0>(pr, ord, n_rem, 0);

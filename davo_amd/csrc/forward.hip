@@ -224,7 +224,7 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         if (layer_h3_mainrem_supported(li, pm, n_main, n_rem)) {
             {
                 ProfScope ps(c, L.label);
-                HIP_TRY(c, launch_layer_h3_mainrem(li, pm, n_main, pr, n_rem, c->stream));
+                HIP_TRY(c, launch_layer_h3_mainrem(li, pm, n_main, pr, n_rem, c->opt_merge_order, c->stream));
             }
             c->last_plan[li][0] = ((plan[0].rows + plan[1].rows + 127) / 128) * 1000 + 7;     // 7: 256x256 + 128x128 in one grid
             return DAVO_OK;

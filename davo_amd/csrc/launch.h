@@ -26,7 +26,8 @@ hipError_t launch_layer_h3(int layer, int tile, const ConvParamsH& p, dim3 grid,
 // (conv_igemm_h3_mainrem); hipErrorNotSupported when the two launches do not have that shape: the caller issues them separately
 // whether launch_layer_h3_mainrem would issue this shape (asked BEFORE the profiling scope of the launch is opened)
 bool layer_h3_mainrem_supported(int layer, const ConvParamsH& pm, int n_main, int n_rem);
-hipError_t launch_layer_h3_mainrem(int layer, const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, hipStream_t s);
+// order: 0 = the short tiles' offset inside every XCD (round 2), 1 = per XCD (even XCDs short tiles first, odd XCDs last)
+hipError_t launch_layer_h3_mainrem(int layer, const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, int order, hipStream_t s);
 // launch_h3s.hip: conv_igemm_h3s (TILE_208x256) for layer 4..6 = cnv5, cnv6, cnv7
 hipError_t launch_layer_h3s(int layer, const ConvParamsH& p, dim3 grid, hipStream_t s);
 hipError_t launch_h3_generic(int KS, int stride, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s);

@@ -33,7 +33,7 @@ bool mainrem_ok(const ConvParamsH& pm, int n_main, int n_rem) {
 }
 
 template <int LAYER, int TNM = 4>
-hipError_t launch_mainrem(const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, hipStream_t s) {
+hipError_t launch_mainrem(const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, int order, hipStream_t s) {
     using namespace h3impl;
     constexpr int RATE = layer_rate(LAYER);
     using TM_ = TileH<4, 2, 2, TNM, 2>;
@@ -45,7 +45,7 @@ hipError_t launch_mainrem(const ConvParamsH& pm, int n_main, const ConvParamsH& 
     auto kern = conv_igemm_h3_mainrem<LAYER, RATE, TNM>;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_main + n_rem), dim3(TM_::THREADS), lds, s, pm, pr, n_main, n_rem);
+    hipLaunchKernelGGL(kern, dim3(n_main + n_rem), dim3(TM_::THREADS), lds, s, pm, pr, n_main, n_rem, order);
     return hipGetLastError();
 }
 
@@ -58,10 +58,11 @@ bool layer_h3_mainrem_supported(int layer, const ConvParamsH& pm, int n_main, in
     return false;
 }
 
-hipError_t launch_layer_h3_mainrem(int layer, const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, hipStream_t s) {
-    if (layer == 3) return launch_mainrem<4, 2>(pm, n_main, pr, n_rem, s);     // cnv4: 256x128 main tiles (N = 128)
-    if (layer == 4) return launch_mainrem<5>(pm, n_main, pr, n_rem, s);
-    if (layer == 5) return launch_mainrem<6>(pm, n_main, pr, n_rem, s);
+hipError_t launch_layer_h3_mainrem(int layer, const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, int order, hipStream_t s) {
+    if (order == 1 && (n_rem % 8 || n_main % 8)) order = 0;
+    if (layer == 3) return launch_mainrem<4, 2>(pm, n_main, pr, n_rem, order, s);     // cnv4: 256x128 main tiles (N = 128)
+    if (layer == 4) return launch_mainrem<5>(pm, n_main, pr, n_rem, order, s);
+    if (layer == 5) return launch_mainrem<6>(pm, n_main, pr, n_rem, order, s);
     return hipErrorNotSupported;
 }
 

@@ -796,6 +796,14 @@ def test_merged_main_and_remainder_launch_is_bit_identical(c_oracle):
     assert np.array_equal(e.debug_read("cnv6", (2 * B, 32, 104, 256)), a6)
     assert np.array_equal(got, base)
     assert_pose_close(got[:4], c_oracle.forward(cfg, img[:4], flow[:4], seg[:4], weights), "merged launch")
+    # the other workgroup-id orders of the same grid, and cnv4 as a merged grid (256x128 + 128x128): the same bits
+    a4 = e.debug_read("cnv4", (2 * B, 32, 104, 128)).copy()
+    for key, val in (("merge_order", 1), ("merge_cnv4", 1)):
+        e.set_option(key, val)
+        assert np.array_equal(e.forward(img, flow, seg), base), key
+        assert np.array_equal(e.debug_read("cnv4", (2 * B, 32, 104, 128)), a4), key
+        assert np.array_equal(e.debug_read("cnv5", (2 * B, 32, 104, 256)), a5) and np.array_equal(e.debug_read("cnv6", (2 * B, 32, 104, 256)), a6), key
+    assert [t for _, t in e.last_plan(3)] == [7]
     e.close()
 
 
