@@ -6,8 +6,25 @@
 #include <cstdio>
 #include <cstdlib>
 
-__global__ __launch_bounds__(256) void probe(const float* __restrict__ in, unsigned* __restrict__ bad, int iters, float scale) {
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// mode 1: every other workgroup keeps the matrix pipe of its SIMDs busy (as the neighbouring workgroups' K loops do in the real launch)
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ in, unsigned* __restrict__ bad, int iters, float scale, int mode, float* sink) {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    if (mode == 1 && (blockIdx.x & 1)) {
+        half8 a, b;
+        for (int k = 0; k < 8; ++k) { a[k] = (_Float16)in[(t * 8 + k) & 1023]; b[k] = (_Float16)in[(t * 8 + k + 5) & 1023]; }
+        f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+        for (int it = 0; it < iters * 2; ++it) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c3, 0, 0, 0);
+        }
+        sink[t] = c0[0] + c1[1] + c2[2] + c3[3];
+        return;
+    }
     float s0 = in[t * 8 + 0], s1 = in[t * 8 + 1], w0 = in[t * 8 + 2], w1 = in[t * 8 + 3], w2 = in[t * 8 + 4];
     unsigned long long sc = __float_as_uint(scale);
     unsigned nbad[6] = {0, 0, 0, 0, 0, 0};
@@ -44,19 +61,20 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ in, unsig
 
 int main(int argc, char** argv) {
     const int wps = argc > 1 ? atoi(argv[1]) : 4;                          // waves per SIMD: blocks of 4 waves, wps blocks per CU
+    const int mode = argc > 2 ? atoi(argv[2]) : 0;
     const int nblk = 256 * wps, n = nblk * 256, iters = 20000;
     float* h = (float*)malloc((size_t)n * 8 * sizeof(float));
     srand(7);
     for (int i = 0; i < n * 8; ++i) h[i] = (float)rand() / RAND_MAX * 4.f - 2.f;
-    float* d; unsigned* bad;
-    hipMalloc(&d, (size_t)n * 8 * sizeof(float)); hipMalloc(&bad, 6 * sizeof(unsigned));
+    float* d; unsigned* bad; float* sink;
+    hipMalloc(&d, (size_t)n * 8 * sizeof(float)); hipMalloc(&bad, 6 * sizeof(unsigned)); hipMalloc(&sink, (size_t)n * sizeof(float));
     hipMemcpy(d, h, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemset(bad, 0, 6 * sizeof(unsigned));
-        hipLaunchKernelGGL(probe, dim3(nblk), dim3(256), 0, 0, d, bad, iters, 0.0078125f);
+        hipLaunchKernelGGL(probe, dim3(nblk), dim3(256), 0, 0, d, bad, iters, 0.0078125f, mode, sink);
         unsigned out[6];
         hipMemcpy(out, bad, sizeof out, hipMemcpyDeviceToHost);
-        printf("waves/SIMD %d, %d lanes x %d rounds: disagreements per output q0..q5 = %u %u %u %u %u %u\n", wps, n, iters, out[0], out[1], out[2], out[3], out[4], out[5]);
+        printf("mode %d, waves/SIMD %d, %d lanes x %d rounds: disagreements per output q0..q5 = %u %u %u %u %u %u\n", mode, wps, n, iters, out[0], out[1], out[2], out[3], out[4], out[5]);
     }
     return 0;
 }
