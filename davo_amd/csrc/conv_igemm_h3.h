@@ -700,6 +700,9 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
                     }
             }
             s0 *= p.out_scale; s1 *= p.out_scale;
+            // every outstanding memory operation of the wave has landed and the pipes have idled a few cycles before the six products are
+            // formed: with this drain even the builds that flaked here were stable ("A flaky sum"; once per tile column group)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15" : "+v"(s0), "+v"(s1));
             q[0] += s0 * w0; q[1] += s0 * w1; q[2] += s0 * w2;
             q[3] += s1 * w0; q[4] += s1 * w1; q[5] += s1 * w2;
         }
