@@ -572,6 +572,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "fold_tails") c->opt_fold_tails = value < 0 ? -1 : (value > 2 ? 1 : value);
     else if (k == "deep_ring") c->opt_deep_ring = value != 0;
     else if (k == "split_k") c->opt_split_k = value != 0;
+    else if (k == "f32_n16") c->opt_f32_n16 = value != 0;
     else if (k == "auto_range") { int rc = judge_pending(c); if (rc) return rc; c->opt_auto_range = value != 0; }
     else if (k == "force_tile") {
         // test hook: every f16x3 layer the tile fits runs as ONE launch of that tile shape (plan.h tile ids; -1 = planner)

@@ -43,6 +43,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <int KS, int STRIDE, int BN, int LAYER>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     using T = Tile<BN>;
+    constexpr bool N16 = BN == 16;             // 16 output columns: four waves of 32 x 16 on v_mfma_f32_16x16x4_f32
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][LDK]
     float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     // Staging registers are named scalars, not arrays: hipcc (ROCm 7.2) keeps a conditionally
     // written float4 array in scratch and serialises every load behind a scratch store.
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define DAVO_LOAD_A(j_, dst_)                                                                      \
     {                                                                                              \
         const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         const bool tap_ok = tap < p.ntaps;                                                         \
         DAVO_LOAD_A(0, ra0) DAVO_LOAD_A(1, ra1) DAVO_LOAD_A(2, ra2) DAVO_LOAD_A(3, ra3)            \
         const float* wrow = wg + (long)r0 * p.Kpad + kg;                                           \
-        rb0 = *reinterpret_cast<const float4*>(wrow);                                              \
+        if (!N16 || r0 < 16) rb0 = *reinterpret_cast<const float4*>(wrow);                         \
         if constexpr (T::NB_LOADS > 1) rb1 = *reinterpret_cast<const float4*>(wrow + 32L * p.Kpad); \
         if constexpr (T::NB_LOADS > 2) {                                                           \
             rb2 = *reinterpret_cast<const float4*>(wrow + 64L * p.Kpad);                           \
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         *reinterpret_cast<float4*>(a_ + 32 * LDK) = ra1;                                           \
         *reinterpret_cast<float4*>(a_ + 64 * LDK) = ra2;                                           \
         *reinterpret_cast<float4*>(a_ + 96 * LDK) = ra3;                                           \
-        *reinterpret_cast<float4*>(b_) = rb0;                                                      \
+        if (!N16 || r0 < 16) *reinterpret_cast<float4*>(b_) = rb0;                                 \
         if constexpr (T::NB_LOADS > 1) *reinterpret_cast<float4*>(b_ + 32 * LDK) = rb1;            \
         if constexpr (T::NB_LOADS > 2) {                                                           \
             *reinterpret_cast<float4*>(b_ + 64 * LDK) = rb2;                                       \
@@ -130,6 +131,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     // front of every guarded store, and on gfx950 vmcnt counts stores too — the epilogue's stores
     // would complete one by one.
     f32x16 acc[T::TM][T::TN];
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    f32x4_t acc16[2];                          // N16: rows 16 i + 4 (lane >> 4) + r of the wave's 32, column lane & 15
+    const int l16 = lane & 15, q16 = lane >> 4;
+    if constexpr (N16) {
+        const float bv = bg[l16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[i][r] = bv;
+    } else {
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const float bv = bg[wn * T::TN * 32 + j * 32 + li];
@@ -138,12 +149,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
     }
+    }
 
     DAVO_LOAD_CHUNK(0)
     DAVO_STORE_CHUNK(0)
     __syncthreads();
 
+    // N16: lane (l16, q16) feeds row / column l16 and k = 16 g + 4 q16 + t of the chunk to step t of group g (any assignment of the
+    // chunk's 32 k to (group, step, lane quarter) is a valid order of the same float32 fma chain, fixed for every batch size)
+#define DAVO_COMPUTE16(buf_)                                                                       \
+    {                                                                                              \
+        const float* a = As + (buf_) * BM * LDK + (wm * 32 + l16) * LDK + 4 * q16;                 \
+        const float* b = Bs + (buf_) * BN * LDK + l16 * LDK + 4 * q16;                             \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                            \
+            const float4 fb = *reinterpret_cast<const float4*>(b + g * 16);                        \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                        \
+                const float4 fa = *reinterpret_cast<const float4*>(a + i * 16 * LDK + g * 16);     \
+                acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, fb.x, acc16[i], 0, 0, 0);    \
+                acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, fb.y, acc16[i], 0, 0, 0);    \
+                acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, fb.z, acc16[i], 0, 0, 0);    \
+                acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, fb.w, acc16[i], 0, 0, 0);    \
+            }                                                                                      \
+        }                                                                                          \
+    }
 #define DAVO_COMPUTE(buf_)                                                                         \
+    if constexpr (N16) DAVO_COMPUTE16(buf_) else                                                   \
     {                                                                                              \
         const float* a = As + (buf_) * BM * LDK + (wm * T::TM * 32 + li) * LDK + 4 * lh;           \
         const float* b = Bs + (buf_) * BN * LDK + (wn * T::TN * 32 + li) * LDK + 4 * lh;           \
@@ -174,6 +204,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     }
     DAVO_COMPUTE((p.nchunks - 1) & 1)
 
+    if constexpr (N16) {       // C/D layout of 16x16x4: col = lane & 15, row = 4 (lane >> 4) + r
+        const int n = ntile * BN + l16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mtile * BM + wm * 32 + i * 16 + 4 * q16 + r;
+                float v = acc16[i][r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (n < p.Cout && m < p.M) yg[(long)m * p.y_ld + n] = v;
+            }
+        return;
+    }
     // ---- epilogue: bias + ReLU, C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
@@ -197,5 +240,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
 #undef DAVO_LOAD_CHUNK
 #undef DAVO_STORE_CHUNK
 #undef DAVO_COMPUTE
+#undef DAVO_COMPUTE16
 
 }  // namespace davo

@@ -96,6 +96,7 @@ struct davo_ctx {
     int opt_merge_order = 0;                   // merged grids: 0 = short tiles offset inside every XCD, 1 = per XCD (conv_igemm_h3_mainrem)
     bool opt_merge_cnv4 = false;               // f16x3: cnv4 as whole rounds of 256x128 tiles + 128x128 remainder tiles in one grid where the batch allows
     bool opt_share_taps = true;                // f16x3: cnv3..cnv6 stage one pixel patch per filter row for its three taps
+    bool opt_f32_n16 = true;                   // f32 mode: cnv1 (16 output channels) on the 128x16 tile / v_mfma_f32_16x16x4_f32 instead of the padded 128x32 one
     bool opt_split_k = true;                   // f16x3: cnv5 / cnv6 launches of at most half a workgroup per CU split their K loop in two (forward.hip)
     float* d_splitk = nullptr;                 // split-K partial sums [4 slots][M][2][N] float32
     size_t splitk_floats = 0;                  // ... per slot

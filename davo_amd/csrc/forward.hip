@@ -130,11 +130,12 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
         p.g_w = (long)L.npad * L.kpad; p.g_bias = L.npad;
     }
     const int mtiles = (p.M + BM - 1) / BM;
-    const std::vector<Launch> plan = plan_layer(mtiles, L.npad, L.groups, c->ncu);
+    std::vector<Launch> plan = plan_layer(mtiles, L.npad, L.groups, c->ncu);
+    if (li == 0 && L.cout <= 16 && c->opt_f32_n16) plan = {{0, mtiles, 16}};      // cnv1 on the 128x16 tile at every batch size (conv_igemm.h, N16)
     c->last_plan[li][0] = c->last_plan[li][1] = 0;
     for (size_t i = 0; i < plan.size(); ++i) {
         p.mtile0 = plan[i].mtile0;
-        p.ntiles_n = L.npad / plan[i].BN;
+        p.ntiles_n = plan[i].BN == 16 ? 1 : L.npad / plan[i].BN;
         dim3 grid(plan[i].mtiles * p.ntiles_n, L.groups);
         const std::string label = i == 0 ? std::string(L.label) : std::string(L.label) + ".rem";
         ProfScope ps(c, label.c_str());

@@ -46,6 +46,7 @@ hipError_t launch_conv(int KS, int stride, int BN, const ConvParams& p, dim3 gri
 }
 
 hipError_t launch_layer(int layer, int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
+    if (layer == 0 && BN == 16) return launch_conv_t<7, 2, 16, 1>(p, grid, s);      // cnv1: 16 output channels, no padded columns
     switch (layer) {
         case 0: return launch_bn<7, 2, 1>(BN, p, grid, s);
         case 1: return launch_bn<5, 2, 2>(BN, p, grid, s);

@@ -41,6 +41,13 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDK = 36;          // padded LDS row (floats)
 
+// BN = 16 (round 3): cnv1 has 16 output channels; on the 32-column tile half of every matrix instruction was padding.  Four waves of
+// 32 rows x 16 columns on v_mfma_f32_16x16x4_f32 (conv_igemm.h).
+template <int BN> struct Tile;
+template <> struct Tile<16> {
+    static constexpr int WN = 1, WM = 4, TM = 1, TN = 1, NB_LOADS = 1;
+    static constexpr int LDS_BYTES = 2 * (128 + 16) * 36 * 4;
+};
 template <int BN> struct Tile {
     static constexpr int WN = BN >= 64 ? 2 : 1;    // waves along N
     static constexpr int WM = 4 / WN;              // waves along M

@@ -195,6 +195,8 @@ int davo_range_stats(davo_ctx* ctx, long long* recalibrations, long long* f32_ba
  *       layer's outputs - and so the poses - agree with the single chain to float32 rounding (~1e-7 relative), not to the
  *       bit; 0 = one K chain at every batch size (poses then do not depend on how windows are batched, with "fuse_pose" 0
  *       to the bit).
+ *   "f32_n16" (default 1; float32 mode): cnv1 (16 output channels) on a 128x16 tile with v_mfma_f32_16x16x4_f32 instead of the
+ *       128x32 tile whose matrix instructions were half padding.  Another order of the same float32 fma chain per output.
  *   "merge_order" (default 0): where the merged grid takes its offset: 0 = inside every XCD (half of each XCD's CUs run their
  *       short tile first), 1 = per XCD (even XCDs first, odd XCDs last: an XCD's CUs stay in step, a fifth fewer L2 misses,
  *       0.5 % slower).  Bit-identical results.
