@@ -187,7 +187,11 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         const size_t need = (size_t)L.groups * mt * ntn * 6;
         if (need > c->pose_tiles_floats) {
             if (c->d_pose_tiles) { int rs = sync_all_slots(c); if (rs) return rs; HIP_TRY(c, hipFree(c->d_pose_tiles)); c->d_pose_tiles = nullptr; }
+#ifdef DAVO_POSE_DEBUG
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_pose_tiles), need * sizeof(float) * 4 + (size_t)L.groups * mt * ntn * 512 * 20 * sizeof(float)));
+#else
             HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_pose_tiles), need * sizeof(float) * 4));   // x4: one region per in-flight slot
+#endif
             c->pose_tiles_floats = need;
         }
         const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;      // the slot this batch runs in
