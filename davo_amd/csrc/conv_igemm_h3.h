@@ -659,9 +659,6 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
     }
 
     if (H3_DBG(32)) return;                                       // measurement only: no epilogue
-#if DAVO_POSE_EXP == 1                             /* idle cycles between the last matrix instruction and the first accumulator access */
-    if (p.y_mode == 2) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
     // ---- epilogues.  Both accumulator layouts are walked through the same three helpers:
     //   column group jj -> column inside the wave tile; (row group ii, register r) -> row inside the wave tile
     constexpr int NCG = M16 ? 2 * TN : TN, NRG = M16 ? 2 * TM : TM, NREG = M16 ? 4 : 16;
@@ -709,15 +706,18 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
                     }
             }
             s0 *= p.out_scale; s1 *= p.out_scale;
-            // every outstanding memory operation of the wave has landed and the pipes have idled a few cycles before the six products are
-            // formed: with this drain even the builds that flaked here were stable ("A flaky sum"; once per tile column group)
-#ifndef DAVO_POSE_NO_DRAIN
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15" : "+v"(s0), "+v"(s1));
-#endif
-#if DAVO_POSE_EXP == 2 || DAVO_POSE_EXP == 4      /* scalar products (an asm barrier after each) */
-            q[0] += s0 * w0; asm volatile("" : "+v"(q[0])); q[1] += s0 * w1; asm volatile("" : "+v"(q[1])); q[2] += s0 * w2; asm volatile("" : "+v"(q[2]));
-            q[3] += s1 * w0; asm volatile("" : "+v"(q[3])); q[4] += s1 * w1; asm volatile("" : "+v"(q[4])); q[5] += s1 * w2; asm volatile("" : "+v"(q[5]));
-#elif DAVO_POSE_EXP >= 5   /* the packed sequence of the flaking builds, written out: 5 = (q4, q5) formed IN PLACE on the (s0, s1) pair, 6 = into another pair, 7 = 5 with idle cycles in front of it */
+            // (No drain, no idle cycles here any more: the round-3 flaky sums were one instruction form, below.)
+#if DAVO_POSE_EXP == 0
+            q[0] += s0 * w0; q[1] += s0 * w1; q[2] += s0 * w2;
+            q[3] += s1 * w0; q[4] += s1 * w1; q[5] += s1 * w2;
+#else
+            // Reproducer builds only (tools/build_variant.py _e6 -DDAVO_POSE_EXP=6; tools/exp/flake_count.py, flake_lanes.py;
+            // DESIGN.md section 3; profiles/r04_flake*_variants.log).  The six products as the packed sequence hipcc's SLP
+            // vectoriser formed here.  6: (q4, q5) by v_pk_fma_f32 ... op_sel:[0,1,0] - the LOW result lane takes the HIGH register
+            // of the 64-bit src1 pair: with three or more waves per SIMD and neighbours keeping the matrix pipe busy the selected
+            // operand sporadically reads as 0 in lanes 48-63 (the product vanishes, the lane returns its addend): 299 of 299
+            // forwards wrong at B = 4.  8: the same products from an (s1, s1) pair, no select: 0 of 299.  9: the selecting
+            // instruction with a constant-0 addend and scalar sums: 74 of 299.  10: the select on src0 (op_sel:[1,0,0]): 0 of 299.
             {
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 f2 sp = {s0, s1}, w01 = {w0, w1}, w20 = {w2, w0}, w12 = {w1, w2};
@@ -726,27 +726,18 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(q23) : "v"(w20), "v"(sp));
 #if DAVO_POSE_EXP == 6
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(q45) : "v"(w12), "v"(sp));
-#elif DAVO_POSE_EXP == 8      /* the same two products without the low-from-high operand select: a (s1, s1) pair */
+#elif DAVO_POSE_EXP == 8
                 { f2 shh = {s1, s1}; asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(q45) : "v"(w12), "v"(shh)); }
-#elif DAVO_POSE_EXP == 9      /* the selecting instruction forms products only (addend 0), the sums are scalar */
+#elif DAVO_POSE_EXP == 9
                 { f2 t45; asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(t45) : "v"(w12), "v"(sp));
                   q45.x += t45.x; asm volatile("" : "+v"(q45)); q45.y += t45.y; asm volatile("" : "+v"(q45)); }
-#elif DAVO_POSE_EXP == 10     /* the select on src0 instead of src1 */
+#elif DAVO_POSE_EXP == 10
                 asm volatile("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,0,0]" : "+v"(q45) : "v"(w12), "v"(sp));
-#elif DAVO_POSE_EXP == 11     /* two idle states on either side, inside the string */
-                asm volatile("s_nop 1\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]\n\ts_nop 1" : "+v"(q45) : "v"(w12), "v"(sp));
 #else
-#if DAVO_POSE_EXP == 7
-                asm volatile("s_nop 7" : "+v"(sp), "+v"(q45));
-#endif
-                asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel:[0,1,0]" : "+v"(sp) : "v"(w12), "v"(q45));
-                q45 = sp;
+#error "DAVO_POSE_EXP: 6, 8, 9 or 10"
 #endif
                 q[0] = q01.x; q[1] = q01.y; q[2] = q23.x; q[3] = q23.y; q[4] = q45.x; q[5] = q45.y;
             }
-#else
-            q[0] += s0 * w0; q[1] += s0 * w1; q[2] += s0 * w2;
-            q[3] += s1 * w0; q[4] += s1 * w1; q[5] += s1 * w2;
 #endif
 #ifdef DAVO_POSE_DEBUG
             if constexpr (NCG == 2) { if (jj == 0) { dbg_v[10] = q[4]; dbg_v[11] = q[5]; } dbg_v[jj * 5 + 0] = s0; dbg_v[jj * 5 + 1] = s1; dbg_v[jj * 5 + 2] = w0; dbg_v[jj * 5 + 3] = w1; dbg_v[jj * 5 + 4] = w2; }
@@ -769,7 +760,7 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 q[k] += __shfl_down(q[k], o, 64);
-#if DAVO_POSE_EXP >= 3                            /* scalar butterfly */
+#if DAVO_POSE_EXP                                 /* reproducer builds: keep the butterfly scalar whatever the flags */
                 asm volatile("" : "+v"(q[k]));
 #endif
             }

@@ -314,7 +314,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
                     if (row < split_row) s0 += v; else s1 += v;
                 }
                 s0 *= p.out_scale; s1 *= p.out_scale;                // a positive power of two: exact
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15" : "+v"(s0), "+v"(s1));      // as conv_igemm_h3.h's pose epilogue
                 qv[0] += s0 * w0; qv[1] += s0 * w1; qv[2] += s0 * w2;
                 qv[3] += s1 * w0; qv[4] += s1 * w1; qv[5] += s1 * w2;
             }

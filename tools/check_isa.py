@@ -20,6 +20,9 @@ sys.path.insert(0, ROOT)
 from davo_amd._lib import HIPCC_FLAGS                                # noqa: E402  (the library's own device-code flags)
 
 PACKED_F32 = re.compile(r"^\s*(v_pk_(fma|mul|add)_f32)\b")
+# v_pk_*_f32 whose LOW result lane takes the HIGH register of the 64-bit src1 pair (op_sel:[x,1,x]): the one instruction form
+# behind round 3's flaky pose sums (profiles/r04_flake*_variants.log)
+SRC1_SELECT = re.compile(r"^\s*v_pk_(fma|mul|add)_f32\b.*\bop_sel:\[\s*[01]\s*,\s*1\b")
 
 
 def compile_to_asm(out, unit="launch_h3.hip"):
@@ -28,9 +31,13 @@ def compile_to_asm(out, unit="launch_h3.hip"):
 
 
 def check_no_packed_f32(path):
-    """davo_amd/_lib.py, HIPCC_FLAGS: packed float32 arithmetic (compiler-formed v_pk_fma_f32 with op_sel) gave launch-to-launch
-    different sums on gfx950; the library is built without SLP vectorisation and must not contain any."""
-    hits = {}
+    """Two properties, the second the narrow one.  (1) No packed float32 arithmetic at all: the library is built with
+    -fno-slp-vectorize (davo_amd/_lib.py), because (2) cannot be asked of the vectoriser and packed f32 beside matrix instructions
+    buys nothing here (26.35 k vs 26.35 k triplets/s, profiles/r03_noslp_ab.log).  (2) No v_pk_{fma,mul,add}_f32 with
+    op_sel:[x,1,x]: on gfx950 that form's low lane sporadically reads its selected operand as 0 in lanes 48-63 when three or more
+    waves share a SIMD beside matrix-dense neighbours (299 of 299 forwards wrong with it, 0 of 299 with the same products
+    formed without the select: tools/exp/flake_count.py on the DAVO_POSE_EXP builds)."""
+    hits, selects = {}, []
     kernel = None
     for line in open(path):
         m = re.match(r"^(_Z\w+):", line)
@@ -39,7 +46,10 @@ def check_no_packed_f32(path):
         m = PACKED_F32.match(line)
         if m:
             hits[kernel] = hits.get(kernel, 0) + 1
-    return ["%s: %d packed float32 instruction(s)" % (k, n) for k, n in sorted(hits.items(), key=lambda kv: str(kv[0]))]
+        if SRC1_SELECT.match(line):
+            selects.append("%s: `%s': packed float32 with a low-from-high select on src1 (miscomputes on gfx950, DESIGN.md section 3)"
+                           % (kernel, line.strip()))
+    return selects + ["%s: %d packed float32 instruction(s)" % (k, n) for k, n in sorted(hits.items(), key=lambda kv: str(kv[0]))]
 
 
 def check_patch_loops(path):
