@@ -42,7 +42,7 @@ EXPORTS = (
     "davo_last_error", "davo_destroy", "davo_device_malloc", "davo_device_free", "davo_memcpy_h2d",
     "davo_memcpy_d2h", "davo_synchronize", "davo_set_stream", "davo_set_inflight", "davo_profile_enable",
     "davo_profile_reset", "davo_profile_entry", "davo_profile_samples", "davo_last_plan", "davo_set_option", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
-    "davo_host_alloc", "davo_host_free", "davo_host_register", "davo_host_unregister", "davo_calibrate", "davo_activation_range", "davo_set_activation_shifts", "davo_range_stats",
+    "davo_host_alloc", "davo_host_free", "davo_host_register", "davo_host_unregister", "davo_calibrate", "davo_activation_range", "davo_set_activation_shifts", "davo_range_stats", "davo_range_report",
     "davo_comm_unique_id", "davo_comm_init", "davo_comm_size", "davo_allgather_poses", "davo_allgather_poses_device",
     "davo_comm_allreduce", "davo_comm_barrier", "davo_comm_destroy", "davo_plan_layer",
 )
@@ -125,6 +125,8 @@ def lib():
     L.davo_set_activation_shifts.argtypes = [vp, ctypes.POINTER(i)]
     llp = ctypes.POINTER(ctypes.c_longlong)
     L.davo_range_stats.argtypes = [vp, llp, llp, llp]
+    L.davo_range_report.argtypes = [vp]
+    L.davo_range_report.restype = ctypes.c_char_p
     L.davo_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_size_t]
     L.davo_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_size_t]
     L.davo_synchronize.argtypes = [vp]
@@ -152,7 +154,7 @@ def lib():
     L.davo_comm_destroy.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("davo_last_error", "davo_destroy"):
+        if name not in ("davo_last_error", "davo_destroy", "davo_range_report"):
             fn.restype = ctypes.c_int
     _lib = L
     return L

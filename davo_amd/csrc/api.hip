@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
 
 #include "ctx.h"
@@ -95,8 +96,9 @@ int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const d
     activate_slot(c, 0);
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_zeros), 256));
     HIP_TRY(c, hipMemset(c->d_zeros, 0, 256));
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_range), 8 * sizeof(unsigned)));
-    HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_range_base), (1 + RANGE_RING) * 8 * sizeof(unsigned)));
+    HIP_TRY(c, hipMemset(c->d_range_base, 0, (1 + RANGE_RING) * 8 * sizeof(unsigned)));
+    c->d_range = c->d_range_base;
     return DAVO_OK;
 }
 
@@ -141,29 +143,79 @@ int davo_weights_missing(davo_ctx* c) {
 // with the storage scales re-calibrated on that very batch, and if it still leaves the fp16-pair range, on the
 // library's own float32 kernels (davo_set_precision(ctx, 0) for that batch only).  "auto_range" 0 restores the plain
 // DAVO_ERR_RANGE verdict.
+//
+// Device path (round 4).  Every batch davo_forward_device issues owns one slot of a ring of RANGE_RING: a record of its own
+// (zeroed by the forward's first kernel) and, unless the caller declared "stable_inputs", room for a copy of its inputs.  The
+// batch's LAST kernel reads the finished record and, if a layer left the range, copies the inputs it was issued on into the
+// slot (prologue.h: snapshot_inputs_if_range_fails) - in stream order behind the kernels that read them and ahead of anything
+// the caller orders behind the batch, e.g. the next H2D into the same buffers.  A batch in range costs six loads per thread and
+// no copy.  A batch is judged when its slot is needed again, at davo_synchronize, or before anything that changes the scales;
+// a failed verdict re-issues THAT batch from the slot's copy, so a streaming caller that recycles its input buffers still gets
+// float32-grade poses for every batch.  (First built with an unconditional side-stream copy: +1.6 % of the step at B = 32,
+// profiles/r04_snapshot_ab.log.)
 namespace {
 
-constexpr size_t PENDING_CAP = 4096;             // device-path batches remembered between verdicts
+constexpr int RING = RANGE_RING;
 
-int read_range_record(davo_ctx* c, unsigned raw[6]) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(raw, c->d_range, 6 * sizeof(unsigned), hipMemcpyDeviceToHost));
+size_t img_bytes(const davo_ctx* c) { return (size_t)c->H * c->W * 9; }
+size_t flow_bytes(const davo_ctx* c) { return (size_t)c->H * c->W * 8 * sizeof(float); }
+size_t seg_bytes(const davo_ctx* c) { return (size_t)c->H * c->W * 3 * sizeof(float); }
+
+int ensure_ring(davo_ctx* c, bool snapshots) {
+    if (!c->read_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->read_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_range), 8 * sizeof(unsigned), hipHostMallocDefault));
+        for (int r = 0; r < RING; ++r) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[r], hipEventDisableTiming));
+    }
+    if (snapshots && !c->snap_img[0]) {
+        for (int r = 0; r < RING; ++r) {
+            HIP_TRY(c, hipMalloc(&c->snap_img[r], img_bytes(c) * c->max_batch));
+            HIP_TRY(c, hipMalloc(&c->snap_flow[r], flow_bytes(c) * c->max_batch));
+            HIP_TRY(c, hipMalloc(&c->snap_seg[r], seg_bytes(c) * c->max_batch));
+        }
+    }
+    return DAVO_OK;
+}
+
+// a record -> host, on a stream of its own (never behind queued batches, never through the null stream); raw[7] = copy taken
+int read_record(davo_ctx* c, const unsigned* d_rec, unsigned raw[8]) {
+    if (!c->read_stream) { int rc = ensure_ring(c, false); if (rc) return rc; }
+    HIP_TRY(c, hipMemcpyAsync(c->h_range, d_rec, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, c->read_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->read_stream));
+    memcpy(raw, c->h_range, 8 * sizeof(unsigned));
+    return DAVO_OK;
+}
+
+void note_seen(davo_ctx* c, const unsigned raw[6], const int* shifts) {
+    for (int i = 0; i < 6; ++i) {
+        float v;
+        memcpy(&v, &raw[i], sizeof v);
+        const float t = ldexpf(v, -shifts[i]);
+        if (!(t <= c->range_seen[i])) c->range_seen[i] = t;          // NaN / inf records stay visible
+    }
+}
+
+int zero_base_record(davo_ctx* c, hipStream_t s) {
+    HIP_TRY(c, hipMemsetAsync(c->d_range_base, 0, 8 * sizeof(unsigned), s));
     return DAVO_OK;
 }
 
 // power-of-two storage scales from a sample batch: each pass runs the path and moves every layer's largest stored
 // value into [512, 1024).  A layer computed from badly ranged inputs still has about the right magnitude, so each
 // pass fixes at least the first badly ranged layer exactly and the later ones to within a few powers of two.
+// Runs on the base record; every stream must be idle.
 int calibrate_on(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, void* d_pose) {
     int rc = DAVO_OK;
     const int save_precision = c->precision, save_impl = c->impl;
     c->precision = 1; c->impl = 0;
+    c->d_range = c->d_range_base;
     for (int pass = 0; pass < 8 && rc == DAVO_OK; ++pass) {
-        if (hipMemset(c->d_range, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = fail(c, DAVO_ERR_HIP, "hipMemset failed"); break; }
+        if ((rc = zero_base_record(c, c->stream))) break;
         rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
         if (rc) break;
-        unsigned raw[6];
-        if ((rc = read_range_record(c, raw))) break;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, DAVO_ERR_HIP, "hipStreamSynchronize failed"); break; }
+        unsigned raw[8];
+        if ((rc = read_record(c, c->d_range_base, raw))) break;
         bool changed = false;
         for (int i = 0; i < 6; ++i) {
             float v;
@@ -178,69 +230,132 @@ int calibrate_on(davo_ctx* c, int B, const void* d_img, const void* d_flow, cons
         if (!changed) break;
     }
     c->precision = save_precision; c->impl = save_impl;
-    (void)hipMemset(c->d_range, 0, 8 * sizeof(unsigned));
-    c->range_dirty = false;
+    (void)zero_base_record(c, c->stream);
     return rc;
 }
 
-// one batch, synchronously, with a record of its own; -> DAVO_OK, DAVO_ERR_RANGE (the verdict) or a hard error
-int run_judged(davo_ctx* c, const PendingBatch& b) {
-    HIP_TRY(c, hipMemsetAsync(c->d_range, 0, 8 * sizeof(unsigned), c->stream));
+// one batch, synchronously, on the base record; -> DAVO_OK, DAVO_ERR_RANGE (the verdict) or a hard error
+int run_judged(davo_ctx* c, const Ticket& b) {
+    c->d_range = c->d_range_base;
+    { int rc = zero_base_record(c, c->stream); if (rc) return rc; }
     int rc = forward_device(c, b.B, b.img, b.flow, b.seg, b.pose);
     if (rc) return rc;
-    unsigned raw[6];
-    if ((rc = read_range_record(c, raw))) return rc;
-    c->range_dirty = false;
-    return c->last_precision == 1 ? check_range(c, raw) : DAVO_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->last_precision != 1) return DAVO_OK;
+    unsigned raw[8];
+    if ((rc = read_record(c, c->d_range_base, raw))) return rc;
+    rc = check_range(c, raw);
+    if (rc == DAVO_OK) note_seen(c, raw, c->act_shift);
+    return rc;
 }
 
-// Every stream idle.  Re-issue the batches a failed verdict covered (one record serves all batches between two
-// verdicts, so all of them): as issued if the batch is inside the range after all, re-calibrated on itself if not,
-// on the float32 kernels if even that leaves the range (per-layer scales cannot cover e.g. an inf / NaN producing net).
-int recover_batches(davo_ctx* c, const std::vector<PendingBatch>& list) {
-    std::vector<PendingBatch> todo;              // each distinct batch once, in the order of its LAST issue
-    for (size_t i = 0; i < list.size(); ++i) {
-        bool later = false;
-        for (size_t j = i + 1; j < list.size() && !later; ++j) later = list[j] == list[i];
-        if (!later) todo.push_back(list[i]);
-    }
+// A failed verdict: re-issue the batch - as issued if the scales have moved since and now hold it, re-calibrated on itself if
+// not, on the float32 kernels if even that leaves the range (per-layer scales cannot cover e.g. an inf / NaN producing net).
+// Drains every stream first: the re-issue uses slot 0's workspace and the base record.
+int recover_batch(davo_ctx* c, const Ticket& b) {
+    { int rc = sync_all_slots(c); if (rc) return rc; }
+    const std::string verdict = c->err;
     activate_slot(c, 0);
-    for (const PendingBatch& b : todo) {
-        int rc = run_judged(c, b);
-        if (rc == DAVO_ERR_RANGE) {
-            if ((rc = calibrate_on(c, b.B, b.img, b.flow, b.seg, b.pose))) return rc;
-            ++c->n_recalibrations;
-            rc = run_judged(c, b);
-        }
-        if (rc == DAVO_ERR_RANGE) {
-            const int save = c->precision;
-            c->precision = 0;
-            rc = forward_device(c, b.B, b.img, b.flow, b.seg, b.pose);
-            c->precision = save;
-            if (rc == DAVO_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, DAVO_ERR_HIP, "hipStreamSynchronize failed");
-            ++c->n_f32_batches;
-        }
-        if (rc) return rc;
-        ++c->n_reissued;
+    int rc = run_judged(c, b);
+    if (rc == DAVO_ERR_RANGE) {
+        if ((rc = calibrate_on(c, b.B, b.img, b.flow, b.seg, b.pose))) return rc;
+        ++c->n_recalibrations;
+        rc = run_judged(c, b);
+        c->range_report = "re-calibrated: " + verdict;
     }
-    HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned)));
-    c->range_dirty = false;
+    if (rc == DAVO_ERR_RANGE) {
+        const int save = c->precision;
+        c->precision = 0;
+        rc = forward_device(c, b.B, b.img, b.flow, b.seg, b.pose);
+        c->precision = save;
+        if (rc == DAVO_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, DAVO_ERR_HIP, "hipStreamSynchronize failed");
+        ++c->n_f32_batches;
+        c->range_report = "float32 kernels for one batch: " + verdict;
+    }
+    if (rc) return rc;
+    ++c->n_reissued;
     c->err.clear();
     return DAVO_OK;
 }
 
-// Verdict on the f16x3 batches davo_forward_device issued since the last one.  Waits for every stream of the context.
-int judge_pending(davo_ctx* c) {
+// verdict on the oldest unjudged device-path batch (waits for that batch only)
+int judge_front(davo_ctx* c) {
+    const Ticket t = c->tickets.front();
+    c->tickets.pop_front();
+    HIP_TRY(c, hipEventSynchronize(c->ev_done[t.ring]));
+    unsigned raw[8];
+    int rc = read_record(c, c->d_range_base + 8 * (1 + t.ring), raw);
+    if (rc == DAVO_OK) {
+        rc = check_range(c, raw, t.shifts);
+        if (rc == DAVO_OK) note_seen(c, raw, t.shifts);
+        else if (rc == DAVO_ERR_RANGE && c->opt_auto_range) {
+            // the batch's last kernel reached the same verdict on the same record and kept the inputs (prologue.h)
+            if (t.snap && raw[7] != 1u) rc = fail(c, DAVO_ERR_INVALID, "internal: a batch failed its range verdict but its inputs were not kept");
+            else rc = recover_batch(c, t);
+        }
+    }
+    c->ring_busy[t.ring] = false;              // after the re-issue: it read the slot's copy of the inputs
+    return rc;
+}
+
+// every unjudged batch; a failed verdict with "auto_range" 0 does not stop the others from being judged
+int judge_all(davo_ctx* c) {
+    int first = c->sticky_range_rc;
+    std::string first_err = c->sticky_range_err;
+    c->sticky_range_rc = 0; c->sticky_range_err.clear();
+    while (!c->tickets.empty()) {
+        const int rc = judge_front(c);
+        if (rc == DAVO_ERR_RANGE) { if (!first) { first = rc; first_err = c->err; } }
+        else if (rc) { for (auto& t : c->tickets) c->ring_busy[t.ring] = false; c->tickets.clear(); return rc; }
+    }
     { int rc = sync_all_slots(c); if (rc) return rc; }
-    if (!c->range_dirty || !c->d_range) { c->pending.clear(); return DAVO_OK; }
-    unsigned raw[6];
-    HIP_TRY(c, hipMemcpy(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost));
-    c->range_dirty = false;            // judged; the record itself stays readable (davo_activation_range) until the next batch
-    std::vector<PendingBatch> list;
-    list.swap(c->pending);
-    const int rc = check_range(c, raw);
-    if (rc != DAVO_ERR_RANGE || !c->opt_auto_range || list.empty()) return rc;
-    return recover_batches(c, list);
+    if (first) { c->err = first_err; return first; }
+    return DAVO_OK;
+}
+
+// the batch about to be issued takes ring slot ring_next: judge what still holds it (may re-issue: before the slot rotation)
+int ticket_reserve(davo_ctx* c) {
+    while (c->ring_busy[c->ring_next]) {
+        const int rc = judge_front(c);
+        if (rc == DAVO_ERR_RANGE && !c->opt_auto_range) {          // reported by the next davo_synchronize; this batch is issued all the same
+            if (!c->sticky_range_rc) { c->sticky_range_rc = rc; c->sticky_range_err = c->err; }
+        } else if (rc) return rc;
+    }
+    return DAVO_OK;
+}
+
+// ... the batch's kernels record into the slot's record; its last kernel keeps the inputs there if the record fails
+int ticket_begin(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, bool* snap) {
+    const int r = c->ring_next;
+    *snap = c->opt_auto_range && !c->opt_stable_inputs;
+    { int rc = ensure_ring(c, *snap); if (rc) return rc; }
+    c->d_range = c->d_range_base + 8 * (1 + r);
+    c->range_zero = true;
+    c->snap = SnapArgs{};
+    if (*snap) {
+        if (((uintptr_t)d_img | (uintptr_t)d_flow | (uintptr_t)d_seg) & 15) return fail(c, DAVO_ERR_INVALID, "device input buffers must be 16-byte aligned");
+        c->snap = SnapArgs{c->d_range, static_cast<const uint8_t*>(d_img), static_cast<const uint8_t*>(d_flow), static_cast<const uint8_t*>(d_seg),
+                           static_cast<uint8_t*>(c->snap_img[r]), static_cast<uint8_t*>(c->snap_flow[r]), static_cast<uint8_t*>(c->snap_seg[r]),
+                           (unsigned)(img_bytes(c) / 16), (unsigned)(flow_bytes(c) / 32), (unsigned)(flow_bytes(c) / 16), (unsigned)(seg_bytes(c) / 16), B};
+    }
+    return DAVO_OK;
+}
+
+int ticket_end(davo_ctx* c, int rc, int B, const void* d_img, const void* d_flow, const void* d_seg, void* d_pose, bool snap) {
+    const int r = c->ring_next;
+    c->d_range = c->d_range_base;
+    c->range_zero = false;
+    c->snap = SnapArgs{};
+    if (rc) return rc;
+    if (c->f32_fallback) ++c->n_f32_batches;
+    if (c->last_precision != 1) return DAVO_OK;                                  // float32 kernels (weight guard): no record, no verdict
+    HIP_TRY(c, hipEventRecord(c->ev_done[r], c->stream));
+    Ticket t{B, snap ? c->snap_img[r] : d_img, snap ? c->snap_flow[r] : d_flow, snap ? c->snap_seg[r] : d_seg, d_pose, r, snap, {}};
+    for (int i = 0; i < 6; ++i) t.shifts[i] = c->act_shift[i];
+    c->tickets.push_back(t);
+    c->ring_busy[r] = true;
+    c->ring_next = (r + 1) % RING;
+    return DAVO_OK;
 }
 
 }  // namespace
@@ -248,18 +363,20 @@ int judge_pending(davo_ctx* c) {
 int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg,
                         void* d_pose, float* elapsed_ms) {
     if (!c) return DAVO_ERR_INVALID;
+    if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
+    if (!d_img || !d_flow || !d_seg || !d_pose) return fail(c, DAVO_ERR_INVALID, "null device pointer");
     HIP_TRY(c, hipSetDevice(c->device));
-    // the list of unjudged batches is bounded: a caller that never synchronises gets a verdict every PENDING_CAP batches
-    if (c->pending.size() >= PENDING_CAP) { int rc = judge_pending(c); if (rc) return rc; }
+    const bool ticketed = c->impl == 0 && c->precision == 1;      // f16x3: the batch gets a record (and a copy of its inputs) of its own
+    if (ticketed) { int rc = ticket_reserve(c); if (rc) return rc; }
     // rotate through the in-flight slots: this batch runs on its own stream and workspace
     activate_slot(c, c->next_slot);
     c->next_slot = (c->next_slot + 1) % c->inflight;
-    // first batch since the last verdict: no unjudged batch is in flight, so the record can start afresh
-    if (!c->range_dirty && c->d_range) HIP_TRY(c, hipMemsetAsync(c->d_range, 0, 8 * sizeof(unsigned), c->stream));
-    const PendingBatch me{B, d_img, d_flow, d_seg, d_pose};
+    bool snap = false;
+    if (ticketed) { int rc = ticket_begin(c, B, d_img, d_flow, d_seg, &snap); if (rc) return rc; }
     if (!elapsed_ms) {
-        const int rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
-        if (rc == DAVO_OK && c->last_precision == 1 && c->opt_auto_range) c->pending.push_back(me);
+        int rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
+        if (ticketed) rc = ticket_end(c, rc, B, d_img, d_flow, d_seg, d_pose, snap);
+        else if (rc == DAVO_OK && c->f32_fallback) ++c->n_f32_batches;
         return rc;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -277,9 +394,9 @@ int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flo
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    if (rc == DAVO_OK && c->last_precision == 1 && c->opt_auto_range) c->pending.push_back(me);
+    if (ticketed) rc = ticket_end(c, rc, B, d_img, d_flow, d_seg, d_pose, snap);
     // the timed form is synchronous, so it can judge (and, if need be, re-issue) its own batch; elapsed_ms is the first issue's
-    if (rc == DAVO_OK && c->inflight == 1) rc = judge_pending(c);
+    if (rc == DAVO_OK && c->inflight == 1) rc = judge_all(c);
     return rc;
 }
 
@@ -299,9 +416,10 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
         HIP_TRY(c, hipMalloc(&c->s_pose, (size_t)c->max_batch * 12 * sizeof(float)));
     }
     if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    { int rc = judge_pending(c); if (rc) return rc; }           // device-path batches issued before this call
+    { int rc = judge_all(c); if (rc) return rc; }               // device-path batches issued before this call
     activate_slot(c, 0);
-    HIP_TRY(c, hipMemsetAsync(c->d_range, 0, 8 * sizeof(unsigned), c->stream));      // the monitor covers this call
+    c->d_range = c->d_range_base;
+    HIP_TRY(c, hipMemsetAsync(c->d_range_base, 0, 8 * sizeof(unsigned), c->stream));      // one record covers this call's sub-batches
     // Sub-batches: the copy of chunk i+1 (copy_stream) overlaps the kernels of chunk i (compute stream).
     // Results do not depend on the split (windows are independent; tests/test_hip_parity.py batch invariance).
     // Only flow planes 0 and 1 are read by the path (davo.py:978-982), so only those cross PCIe.
@@ -312,6 +430,7 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
         HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->copy_done.push_back(e);
     }
+    bool f32_fallback = false;
     for (int i = 0; i < nchunks; ++i) {
         const int b0 = i * chunk, nb = std::min(chunk, B - b0);
         uint8_t* di = (uint8_t*)c->s_img + nb_img * b0;
@@ -325,17 +444,20 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_done[i], 0));
         int rc = forward_device(c, nb, di, (const float*)df, (const float*)ds, (float*)c->s_pose + (size_t)b0 * 12);
         if (rc) return rc;
+        f32_fallback |= c->f32_fallback;
     }
+    if (f32_fallback) ++c->n_f32_batches;                      // once per call, not per sub-batch
     HIP_TRY(c, hipMemcpyAsync(pose_out, c->s_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    unsigned raw[6];
-    HIP_TRY(c, hipMemcpyAsync(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->range_dirty = false;                                   // judged here
     if (c->last_precision != 1) return DAVO_OK;
-    int rc = check_range(c, raw);
+    unsigned raw[8];
+    int rc = read_record(c, c->d_range_base, raw);
+    if (rc) return rc;
+    rc = check_range(c, raw);
+    if (rc == DAVO_OK) note_seen(c, raw, c->act_shift);
     if (rc == DAVO_ERR_RANGE && c->opt_auto_range) {
         // the staged copy of the batch is still in HBM: re-issue it whole (recalibrated, or on the float32 kernels)
-        rc = recover_batches(c, {PendingBatch{B, c->s_img, c->s_flow, c->s_seg, c->s_pose}});
+        rc = recover_batch(c, Ticket{B, c->s_img, c->s_flow, c->s_seg, c->s_pose, -1, false, {}});
         if (rc == DAVO_OK) HIP_TRY(c, hipMemcpy(pose_out, c->s_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost));
     }
     return rc;
@@ -352,22 +474,20 @@ int davo_range_stats(davo_ctx* c, long long* recalibrations, long long* f32_batc
 int davo_activation_range(davo_ctx* c, float* max_abs, int* shifts, int reset) {
     if (!c) return DAVO_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    { int rc = sync_all_slots(c); if (rc) return rc; }
-    unsigned raw[6];
-    HIP_TRY(c, hipMemcpy(raw, c->d_range, sizeof raw, hipMemcpyDeviceToHost));
+    { int rc = judge_all(c); if (rc && rc != DAVO_ERR_RANGE) return rc; }      // every issued batch's record is in range_seen now
     for (int i = 0; i < 6; ++i) {
-        float v;
-        memcpy(&v, &raw[i], sizeof v);
-        if (max_abs) max_abs[i] = ldexpf(v, -c->act_shift[i]);
+        if (max_abs) max_abs[i] = c->range_seen[i];
         if (shifts) shifts[i] = c->act_shift[i];
     }
-    if (reset) { HIP_TRY(c, hipMemset(c->d_range, 0, 8 * sizeof(unsigned))); c->range_dirty = false; }
+    if (reset) for (int i = 0; i < 6; ++i) c->range_seen[i] = 0.f;
     return DAVO_OK;
 }
 
+const char* davo_range_report(const davo_ctx* c) { return c ? c->range_report.c_str() : ""; }
+
 int davo_set_activation_shifts(davo_ctx* c, const int* shifts) {
     if (!c) return DAVO_ERR_INVALID;
-    { int rc = sync_all_slots(c); if (rc) return rc; }
+    { int rc = judge_all(c); if (rc) return rc; }             // batches issued under the old scales get their verdict first
     for (int i = 0; i < 6; ++i) {
         const int s = shifts ? shifts[i] : 0;
         if (s < -60 || s > 60) return fail(c, DAVO_ERR_INVALID, "activation shift %d outside [-60,60]", s);
@@ -381,7 +501,7 @@ int davo_calibrate(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
     if (!d_img || !d_flow || !d_seg) return fail(c, DAVO_ERR_INVALID, "null device pointer");
     HIP_TRY(c, hipSetDevice(c->device));
-    { int rc = judge_pending(c); if (rc) return rc; }         // batches issued under the old scales get their verdict first
+    { int rc = judge_all(c); if (rc) return rc; }             // batches issued under the old scales get their verdict first
     activate_slot(c, 0);
     float* d_pose = nullptr;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_pose), (size_t)B * 12 * sizeof(float)));
@@ -407,7 +527,13 @@ void davo_destroy(davo_ctx* c) {
     }
     for (auto e : c->copy_done) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    void* misc[] = {c->d_range, c->d_splitk, c->d_pose_tiles, c->d_w1patch, c->d_w2patch, c->d_w3patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
+    if (c->read_stream) (void)hipStreamDestroy(c->read_stream);
+    if (c->h_range) (void)hipHostFree(c->h_range);
+    for (int r = 0; r < RANGE_RING; ++r) {
+        if (c->ev_done[r]) (void)hipEventDestroy(c->ev_done[r]);
+        for (void* q : {c->snap_img[r], c->snap_flow[r], c->snap_seg[r]}) if (q) (void)hipFree(q);
+    }
+    void* misc[] = {c->d_range_base, c->d_splitk, c->d_pose_tiles, c->d_w1patch, c->d_w2patch, c->d_w3patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
     for (auto& pe : c->prof_entries)
         for (auto& ab : pe.pending) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
@@ -459,9 +585,9 @@ int davo_synchronize(davo_ctx* c) {
     if (!c) return DAVO_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     // f16x3: the batches davo_forward_device issued since the last synchronize are judged here (the asynchronous
-    // entry point cannot know its own result).  A failed verdict re-issues them (recover_batches); with "auto_range" 0
+    // entry point cannot know its own result).  A failed verdict re-issues that batch (recover_batch); with "auto_range" 0
     // it is returned as DAVO_ERR_RANGE = some layer left the fp16-pair storage range
-    return judge_pending(c);
+    return judge_all(c);
 }
 int davo_set_stream(davo_ctx* c, void* hip_stream) {
     if (!c) return DAVO_ERR_INVALID;
@@ -573,7 +699,8 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "deep_ring") c->opt_deep_ring = value != 0;
     else if (k == "split_k") c->opt_split_k = value != 0;
     else if (k == "f32_n16") c->opt_f32_n16 = value != 0;
-    else if (k == "auto_range") { int rc = judge_pending(c); if (rc) return rc; c->opt_auto_range = value != 0; }
+    else if (k == "auto_range") { int rc = judge_all(c); if (rc) return rc; c->opt_auto_range = value != 0; }
+    else if (k == "stable_inputs") { int rc = judge_all(c); if (rc) return rc; c->opt_stable_inputs = value != 0; }
     else if (k == "force_tile") {
         // test hook: every f16x3 layer the tile fits runs as ONE launch of that tile shape (plan.h tile ids; -1 = planner)
         if (value < -1 || value >= NUM_TILES) return fail(c, DAVO_ERR_INVALID, "force_tile must be -1..%d", NUM_TILES - 1);

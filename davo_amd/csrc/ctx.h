@@ -18,6 +18,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -66,12 +67,18 @@ struct Slot {
     unsigned* d_counters = nullptr;              // "last workgroup" tickets (pose_tail.h): [0] cnv7's pose tail, [1 + b] triplet b's squeeze
 };
 
-// A batch davo_forward_device has issued and no verdict on its f16x3 range record has covered yet
-struct PendingBatch {
+// A batch davo_forward_device has issued whose f16x3 range record has not been judged yet.  Every such batch owns one slot of a
+// small ring: a range record of its own and - unless the caller declared its inputs stable - room for a context-owned copy of
+// its inputs, which the batch's last kernel fills if (and only if) the record will fail the verdict, so that the re-issue reads
+// exactly what was issued whatever the caller has done to its buffers since (api.hip, prologue.h).
+constexpr int RANGE_RING = 4;
+struct Ticket {
     int B;
-    const void *img, *flow, *seg;
+    const void *img, *flow, *seg;              // what a re-issue reads: the ring slot's snapshot, or the caller's buffers ("stable_inputs")
     void* pose;
-    bool operator==(const PendingBatch& o) const { return B == o.B && img == o.img && flow == o.flow && seg == o.seg && pose == o.pose; }
+    int ring;
+    bool snap;                                 // img / flow / seg are the ring slot's copy
+    int shifts[6];                             // storage scales the batch was issued under (davo_activation_range reports true magnitudes)
 };
 
 struct Comm;                                     // comm.hip: RCCL communicator state
@@ -140,12 +147,27 @@ struct davo_ctx {
     // f16x3 range management: activations are stored as fp16 pairs scaled by 2^act_shift[layer] (davo_calibrate);
     // every storing epilogue atomicMax-es the largest stored magnitude into d_range[layer]
     int act_shift[7] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned* d_range = nullptr;               // [8]
-    bool range_dirty = false;                  // an f16x3 forward_device ran since the record was last checked
-    // Range recovery (davo_set_option "auto_range", default on): the device-path batches issued since the last verdict are
-    // remembered so that a failed verdict can re-issue them - recalibrated, or on the float32 kernels (api.hip: recover_batches)
+    unsigned* d_range_base = nullptr;          // [1 + RANGE_RING][8]: record 0 serves the host path, calibration and re-issues; 1.. the ring
+    unsigned* d_range = nullptr;               // the record the next launches write to (one of the above)
+    bool range_zero = false;                   // the next forward's first kernel zeroes that record itself (ticketed device-path batches)
+    // Range recovery (davo_set_option "auto_range", default on): every device-path batch is judged on a record of its own, at the
+    // latest when its ring slot is needed again (RANGE_RING batches later) or at davo_synchronize; a failed verdict re-issues that
+    // batch from the context's own copy of its inputs - recalibrated, or on the float32 kernels (api.hip)
     bool opt_auto_range = true;
-    std::vector<davo::PendingBatch> pending;
+    bool opt_stable_inputs = false;            // "stable_inputs": the caller keeps inputs unchanged until the verdict, no copies are taken
+    std::deque<davo::Ticket> tickets;
+    bool ring_busy[davo::RANGE_RING] = {};
+    int ring_next = 0;
+    void *snap_img[davo::RANGE_RING] = {}, *snap_flow[davo::RANGE_RING] = {}, *snap_seg[davo::RANGE_RING] = {};
+    davo::SnapArgs snap{};                     // set around a ticketed batch: its last kernel copies the inputs if the record fails (prologue.h)
+    hipStream_t read_stream = nullptr;
+    hipEvent_t ev_done[davo::RANGE_RING] = {};
+    unsigned* h_range = nullptr;               // page-locked landing pad of a record read
+    float range_seen[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // largest true |activation| judged since the last reset
+    int sticky_range_rc = 0;                   // "auto_range" 0: a failed verdict met while issuing is reported by the next davo_synchronize
+    std::string sticky_range_err;
+    bool f32_fallback = false;                 // the last forward_device ran the float32 kernels because of the weight guard
+    std::string range_report;                  // what the range management last did, in words (davo_range_report)
     long long n_recalibrations = 0, n_f32_batches = 0, n_reissued = 0;
     int host_chunk = 8;                        // davo_forward: windows per sub-batch (davo_set_option "host_chunk"; 0 = whole batch)
     // profiling
@@ -229,7 +251,7 @@ inline void split_f16(float v, _Float16* hi, _Float16* lo) {
 void activate_slot(davo_ctx* c, int i);
 int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, void* d_pose);
 // f16x3: verdict on the range record (d_range) read back from the device; DAVO_ERR_RANGE names the layer
-int check_range(davo_ctx* c, const unsigned raw[6]);
+int check_range(davo_ctx* c, const unsigned raw[6], const int* shifts = nullptr);
 
 // ---- comm.hip -------------------------------------------------------------------------------
 void comm_release(davo_ctx* c);

@@ -90,18 +90,19 @@ void activate_slot(davo_ctx* c, int i) {
 // f16x3 only.  Stored activations (fp16 hi/lo pairs) are float32-grade while the layer's largest stored value is
 // below the fp16 maximum (above it values were clamped) and not so small that the pairs lose their low bits
 // (tools/exp_activation_scale.py: the 1e-4 bar holds down to ~2^-16 of O(1) activations; 2^-11 is the guard).
-int check_range(davo_ctx* c, const unsigned raw[6]) {
+int check_range(davo_ctx* c, const unsigned raw[6], const int* shifts) {
     static const char* names[6] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6"};
+    if (!shifts) shifts = c->act_shift;              // the scales the judged batch was issued under
     for (int i = 0; i < 6; ++i) {
         float v;
         memcpy(&v, &raw[i], sizeof v);
-        const float actual = ldexpf(v, -c->act_shift[i]);
+        const float actual = ldexpf(v, -shifts[i]);
+        if (!range_value_fails(v)) continue;         // params.h: the same test the batch's last kernel applies (prologue.h)
         if (!(v < 65504.f))
             return fail(c, DAVO_ERR_RANGE, "%s activations reach %.4g: outside the fp16-pair storage range at scale 2^%d "
-                        "(values were clamped) - run davo_calibrate() or davo_set_precision(ctx, 0)", names[i], (double)actual, c->act_shift[i]);
-        if (v > 0.f && v < 0x1p-11f)
-            return fail(c, DAVO_ERR_RANGE, "%s activations are at most %.4g: too small for the fp16-pair storage at scale 2^%d "
-                        "- run davo_calibrate() or davo_set_precision(ctx, 0)", names[i], (double)actual, c->act_shift[i]);
+                        "(values were clamped) - run davo_calibrate() or davo_set_precision(ctx, 0)", names[i], (double)actual, shifts[i]);
+        return fail(c, DAVO_ERR_RANGE, "%s activations are at most %.4g: too small for the fp16-pair storage at scale 2^%d "
+                        "- run davo_calibrate() or davo_set_precision(ctx, 0)", names[i], (double)actual, shifts[i]);
     }
     return DAVO_OK;
 }
@@ -388,6 +389,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->packed_ready) { int rc = build_packed_weights(c); if (rc) return rc; }
     bool h3 = c->impl == 0 && c->precision == 1;
+    c->f32_fallback = false;
     if (h3 && !c->packed_h_ready) { int rc = build_packed_weights_h3(c); if (rc) return rc; }
     if (h3 && c->weight_channel_spread_log2 > MAX_WEIGHT_CHANNEL_SPREAD_LOG2) {
         // a consumer's per-input-channel weight norms span more than 2^14: per-layer storage scales cannot keep every channel's fp16
@@ -397,8 +399,13 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
                         "float32-grade - davo_set_precision(ctx, 0), or leave \"auto_range\" on", c->weight_channel_spread_layer.c_str(),
                         c->weight_channel_spread_log2, MAX_WEIGHT_CHANNEL_SPREAD_LOG2);
         h3 = false;
-        ++c->n_f32_batches;
+        c->f32_fallback = true;              // counted once per API call by the caller (api.hip)
+        char note[256];
+        snprintf(note, sizeof note, "float32 kernels: per-input-channel weight norms of `%s' span 2^%d (> 2^%d)",
+                 c->weight_channel_spread_layer.c_str(), c->weight_channel_spread_log2, MAX_WEIGHT_CHANNEL_SPREAD_LOG2);
+        c->range_report = note;
     }
+    unsigned* const range_reset = (h3 && c->range_zero) ? c->d_range : nullptr;
 
     const int H = c->H, W = c->W, HW = H * W, NB = 2 * B;
     const Variant& v = c->v;
@@ -419,7 +426,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         HIP_TRY(c, launch_se_squeeze_excite(static_cast<const float*>(d_flow), B, HW, v, c->d_partial, c->d_counters + 1,
                                             wdev("pose_exp_net/se_flow/bottleneck_fc/kernel"), wdev("pose_exp_net/se_flow/bottleneck_fc/bias"),
                                             wdev("pose_exp_net/se_flow/recover_fc/kernel"), wdev("pose_exp_net/se_flow/recover_fc/bias"),
-                                            wdev("pose_exp_net/pose_exp_net/seg_channel_weight/weight"), c->d_tab, s));
+                                            wdev("pose_exp_net/pose_exp_net/seg_channel_weight/weight"), c->d_tab, range_reset, s));
     } else if (v.att_source == 1) {
         ProfScope ps(c, "se_squeeze_partial");
         HIP_TRY(c, launch_se_squeeze(static_cast<const float*>(d_flow), B, HW, v, c->d_partial, s));
@@ -429,7 +436,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         HIP_TRY(c, launch_se_excite(c->d_partial, B, HW, v,
                                     wdev("pose_exp_net/se_flow/bottleneck_fc/kernel"), wdev("pose_exp_net/se_flow/bottleneck_fc/bias"),
                                     wdev("pose_exp_net/se_flow/recover_fc/kernel"), wdev("pose_exp_net/se_flow/recover_fc/bias"),
-                                    wdev("pose_exp_net/pose_exp_net/seg_channel_weight/weight"), c->d_tab, s));
+                                    wdev("pose_exp_net/pose_exp_net/seg_channel_weight/weight"), c->d_tab, range_reset, s));
     }
     // f16x3, fuse_pack: cnv1 builds its input patch straight from the raw inputs (mask + pack fused in,
     // the packed tensor never touches HBM).  Measured equal in time to mask_pack + cnv1 (the fused fill is bound
@@ -470,7 +477,6 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         if ((rc = run_conv_layer_h3(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, true, NB, pose_fused, &pose_bm, &pose_mt, &pose_ntn,
                                     fold_pose ? static_cast<float*>(d_pose) : nullptr))) return rc;
         c->cnv7_valid = !pose_fused;
-        c->range_dirty = true;
     } else if (c->impl == 0) {
         if ((rc = run_conv_layer(c, 0, c->d_packed, 8, H, W, a[0], 16, NB))) return rc;
         if ((rc = run_conv_layer(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, NB))) return rc;
@@ -495,16 +501,20 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
             if ((rc = run_direct(c, "cnv7", a[5], NB, c->H2, c->W2, c6, 2 * c6, h * c6, hp + "cnv7/weights", hp + "cnv7/biases", 3, 256, 2, 1, a[6], 512, h * 256))) return rc;
         }
     }
+    bool snap_done = false;
     if (!(pose_fused && fold_pose)) {
         ProfScope ps(c, "pose_head");
         if (pose_fused) {
             const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;
             HIP_TRY(c, launch_pose_from_tiles(c->d_pose_tiles + (size_t)slot_idx * c->pose_tiles_floats, NB, c->H3 * c->W3, pose_bm,
-                                              pose_mt, pose_ntn, c->d_bpred, static_cast<float*>(d_pose), s));
+                                              pose_mt, pose_ntn, c->d_bpred, static_cast<float*>(d_pose), h3 ? c->snap : SnapArgs{}, s));
+            snap_done = true;
         } else {
             HIP_TRY(c, launch_pose_head(a[6], NB, c->H3 * c->W3, c->d_wpred, c->d_bpred, c->d_pose_partial, static_cast<float*>(d_pose), s));
         }
     }
+    // the range guard's conditional copy of this batch's inputs (api.hip: tickets) rides in pose_from_tiles; other pose heads get a launch
+    if (h3 && c->snap.record && !snap_done) HIP_TRY(c, launch_range_guard_snapshot(c->snap, s));
     c->last_B = B;
     c->last_precision = h3 ? 1 : 0;
     return DAVO_OK;

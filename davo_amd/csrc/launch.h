@@ -35,12 +35,12 @@ hipError_t launch_h3_generic(int KS, int stride, int tile, const ConvParamsH& p,
 // ---- launch_misc.hip: prologue, pose head, cnv1 patch kernel, direct convolution ---------------------
 hipError_t launch_se_squeeze(const float* d_flow, int B, int HW, const Variant& v, float* d_partial, hipStream_t s);
 hipError_t launch_se_excite(const float* d_partial, int B, int HW, const Variant& v, const float* w1, const float* b1,
-                            const float* w2, const float* b2, const float* wstatic, float* d_tab, hipStream_t s);
+                            const float* w2, const float* b2, const float* wstatic, float* d_tab, unsigned* d_range_reset, hipStream_t s);
 // squeeze + excitation in one launch: the last workgroup of each triplet evaluates its tables (prologue.h, pose_tail.h);
 // d_counters: one zeroed unsigned per triplet, left at zero
 hipError_t launch_se_squeeze_excite(const float* d_flow, int B, int HW, const Variant& v, float* d_partial, unsigned* d_counters,
                                     const float* w1, const float* b1, const float* w2, const float* b2, const float* wstatic,
-                                    float* d_tab, hipStream_t s);
+                                    float* d_tab, unsigned* d_range_reset, hipStream_t s);
 // ld: 16 = split-fp16 8-channel layout (f16x3), 8 = float32 8-channel, 10 = the reference's 10-channel layout
 hipError_t launch_mask_pack(int ld, const uint8_t* d_img, const float* d_flow, const float* d_seg, const float* d_tab,
                             const Variant& v, int B, int H, int W, float* d_packed, hipStream_t s);
@@ -50,7 +50,9 @@ hipError_t launch_cnv3_patch(const ConvPatchParams& p, int nblk, hipStream_t s);
 // split-K fix-up: d_part [M][S][N] float32 partial sums -> the layer's stored activation (ReLU, fp16 hi/lo pairs, range monitor)
 hipError_t launch_splitk_fixup(const float* d_part, long M, int N, int S, int relu, uint8_t* d_y, unsigned* d_range, hipStream_t s);
 hipError_t launch_pose_from_tiles(const float* d_tiles, int NB, int P, int bm, int mtiles, int ntiles_n,
-                                  const float* d_bpred, float* d_pose, hipStream_t s);
+                                  const float* d_bpred, float* d_pose, const SnapArgs& snap, hipStream_t s);
+// the range guard's conditional copy of the batch's inputs as a launch of its own (prologue.h)
+hipError_t launch_range_guard_snapshot(const SnapArgs& snap, hipStream_t s);
 hipError_t launch_pose_head(const float* d_c7, int NB, int P, const float* d_wpred, const float* d_bpred,
                             float* d_partial, float* d_pose, hipStream_t s);
 hipError_t launch_conv_direct(const float* x, int N, int Hin, int Win, int cin, int x_ld, int x_coff, const float* w, int KS,

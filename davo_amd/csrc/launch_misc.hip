@@ -30,16 +30,16 @@ hipError_t launch_se_squeeze(const float* d_flow, int B, int HW, const Variant& 
 }
 
 hipError_t launch_se_excite(const float* d_partial, int B, int HW, const Variant& v, const float* w1, const float* b1,
-                            const float* w2, const float* b2, const float* wstatic, float* d_tab, hipStream_t s) {
-    hipLaunchKernelGGL(se_excite, dim3(B, 3), dim3(64), 0, s, d_partial, HW, v, w1, b1, w2, b2, wstatic, d_tab);
+                            const float* w2, const float* b2, const float* wstatic, float* d_tab, unsigned* d_range_reset, hipStream_t s) {
+    hipLaunchKernelGGL(se_excite, dim3(B, 3), dim3(64), 0, s, d_partial, HW, v, w1, b1, w2, b2, wstatic, d_tab, d_range_reset);
     return hipGetLastError();
 }
 
 hipError_t launch_se_squeeze_excite(const float* d_flow, int B, int HW, const Variant& v, float* d_partial, unsigned* d_counters,
                                     const float* w1, const float* b1, const float* w2, const float* b2, const float* wstatic,
-                                    float* d_tab, hipStream_t s) {
+                                    float* d_tab, unsigned* d_range_reset, hipStream_t s) {
     hipLaunchKernelGGL(se_squeeze_excite, dim3(SQ_CHUNKS, 2, B), dim3(256), 0, s, d_flow, HW, v, d_partial, d_counters, w1, b1, w2, b2,
-                       wstatic, d_tab);
+                       wstatic, d_tab, d_range_reset);
     return hipGetLastError();
 }
 
@@ -85,8 +85,13 @@ hipError_t launch_splitk_fixup(const float* d_part, long M, int N, int S, int re
 }
 
 hipError_t launch_pose_from_tiles(const float* d_tiles, int NB, int P, int bm, int mtiles, int ntiles_n,
-                                  const float* d_bpred, float* d_pose, hipStream_t s) {
-    hipLaunchKernelGGL(pose_from_tiles, dim3(NB * 6), dim3(64), 0, s, d_tiles, NB, P, bm, mtiles, ntiles_n, d_bpred, d_pose);
+                                  const float* d_bpred, float* d_pose, const SnapArgs& snap, hipStream_t s) {
+    hipLaunchKernelGGL(pose_from_tiles, dim3(NB * 6), dim3(64), 0, s, d_tiles, NB, P, bm, mtiles, ntiles_n, d_bpred, d_pose, snap);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_guard_snapshot(const SnapArgs& snap, hipStream_t s) {
+    hipLaunchKernelGGL(range_guard_snapshot, dim3(256), dim3(256), 0, s, snap);
     return hipGetLastError();
 }
 

@@ -207,4 +207,19 @@ struct ConvPatchParams {
     int dbg;                // measurement only (-DDAVO_TUNING, DAVO_PDBG): 1 = every patch load reads the zero line, 2 = no stores
 };
 
+// ---- f16x3 range guard: the verdict on a batch's record, shared by the host (forward.hip: check_range) and by the kernel
+// that keeps a copy of the batch's inputs when - and only when - that verdict will fail (prologue.h) ------------------------
+__host__ __device__ inline bool range_value_fails(float v) {
+    return !(v < 65504.f) || (v > 0.f && v < 0x1p-11f);        // clamped / inf / NaN, or too small for the fp16 pairs' low halves
+}
+// What the last kernel of a ticketed device-path batch needs to copy the inputs into the context's ring slot (api.hip).
+// record: the batch's 8-word range record ([0..5] cnv1..cnv6, [7] = 1 once the copy was taken); null = no copy wanted.
+struct SnapArgs {
+    unsigned* record;
+    const uint8_t *img, *flow, *seg;        // the caller's buffers (16-byte aligned)
+    uint8_t *s_img, *s_flow, *s_seg;        // the ring slot's
+    unsigned img_vec, flow_vec_half, flow_vec, seg_vec;      // per window, in 16-byte units: strip, flow planes 0-1, whole flow block, seg
+    int B;
+};
+
 }  // namespace davo

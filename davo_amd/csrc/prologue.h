@@ -105,7 +105,10 @@ __global__ __launch_bounds__(64) void se_excite(const float* __restrict__ partia
                                                 const float* __restrict__ w1, const float* __restrict__ b1,
                                                 const float* __restrict__ w2, const float* __restrict__ b2,
                                                 const float* __restrict__ wstatic,
-                                                float* __restrict__ tab) {
+                                                float* __restrict__ tab, unsigned* __restrict__ range_reset) {
+    // a ticketed device-path batch starts its own f16x3 range record (api.hip): first kernel of the forward, so in stream
+    // order before any storing epilogue; a null pointer = the record is the caller's business
+    if (range_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) range_reset[threadIdx.x] = 0u;
     se_excite_wave<false>(partial, HW, v, blockIdx.x, blockIdx.y, threadIdx.x, w1, b1, w2, b2, wstatic, tab);
 }
 
@@ -116,8 +119,10 @@ __global__ __launch_bounds__(256) void se_squeeze_excite(const float* __restrict
                                                          float* __restrict__ partial, unsigned* __restrict__ counters,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
-                                                         const float* __restrict__ wstatic, float* __restrict__ tab) {
+                                                         const float* __restrict__ wstatic, float* __restrict__ tab,
+                                                         unsigned* __restrict__ range_reset) {
     const int chunk = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+    if (range_reset && chunk == 0 && s == 0 && b == 0 && threadIdx.x < 8) range_reset[threadIdx.x] = 0u;      // as se_excite
     const float4* f = reinterpret_cast<const float4*>(flow + ((size_t)b * 4 + s) * HW * 2);
     const int nvec = HW / 2;                                   // HW is a multiple of 16
     const int per = (nvec + SQ_CHUNKS - 1) / SQ_CHUNKS;
@@ -327,13 +332,47 @@ __global__ __launch_bounds__(64) void pose_finish(const float* __restrict__ part
 // partial[head][mtile][ntile][slot][k], slot 0 = the tile's first image, slot 1 = the next one.  One 64-lane wave per
 // output (n, head, k): the tiles' terms are spread over the lanes and added by a fixed butterfly (pose_tail.h) — a
 // single thread walking 56 dependent loads (128x32 tiles at batch 1) took 12 us.
+// Range guard, device side (api.hip: tickets).  The batch's range record is complete when its last kernel runs (stream order), so
+// that kernel can see the verdict the host will reach later: if a layer left the fp16-pair range the batch will be re-issued,
+// and the inputs it was issued on are copied into the context's ring slot NOW - behind the kernels that read them, ahead of
+// anything the caller orders behind the batch (e.g. the H2D of the next batch into the same buffers).  A batch in range -
+// every batch of a well-ranged checkpoint - costs six loads per thread and no copy.  Only flow planes 0 and 1 are read by the
+// path (davo.py:978-982): the first half of every window's block.
+__device__ __forceinline__ void snapshot_inputs_if_range_fails(const SnapArgs& a, unsigned worker, unsigned nworkers) {
+    if (!a.record) return;
+    bool fails = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fails |= range_value_fails(__uint_as_float(__atomic_load_n(a.record + i, __ATOMIC_RELAXED)));
+    if (!fails) return;
+    const uint4* si = reinterpret_cast<const uint4*>(a.img);
+    const uint4* sf = reinterpret_cast<const uint4*>(a.flow);
+    const uint4* ss = reinterpret_cast<const uint4*>(a.seg);
+    uint4* di = reinterpret_cast<uint4*>(a.s_img);
+    uint4* df = reinterpret_cast<uint4*>(a.s_flow);
+    uint4* ds = reinterpret_cast<uint4*>(a.s_seg);
+    const size_t n_img = (size_t)a.img_vec * a.B, n_seg = (size_t)a.seg_vec * a.B, n_flow = (size_t)a.flow_vec_half * a.B;
+    for (size_t i = worker; i < n_img; i += nworkers) di[i] = si[i];
+    for (size_t i = worker; i < n_seg; i += nworkers) ds[i] = ss[i];
+    for (size_t i = worker; i < n_flow; i += nworkers) {
+        const size_t b = i / a.flow_vec_half, o = i - b * a.flow_vec_half;
+        df[b * a.flow_vec + o] = sf[b * a.flow_vec + o];
+    }
+    if (worker == 0) a.record[7] = 1u;                    // the host's verdict will find the copy it needs (checked there)
+}
+
 __global__ __launch_bounds__(64) void pose_from_tiles(const float* __restrict__ partial, int NB, int P, int bm,
                                                       int mtiles, int ntiles_n, const float* __restrict__ bpred,
-                                                      float* __restrict__ pose /*[2B][6]*/) {
+                                                      float* __restrict__ pose /*[2B][6]*/, SnapArgs snap) {
     const int i = blockIdx.x;                              // (n, head, k)
     const int n = i / 6, hk = i - n * 6;
     const float tot = pose_tile_sum<false>(partial, n, hk, P, bm, mtiles, ntiles_n, threadIdx.x);
     if (threadIdx.x == 0) pose[i] = 0.01f * (tot / (float)P + bpred[hk]);
+    snapshot_inputs_if_range_fails(snap, blockIdx.x * 64 + threadIdx.x, gridDim.x * 64);
+}
+
+// the same guard as a launch of its own, behind the pose heads that are not pose_from_tiles ("fuse_pose" 0, "fold_tails" 1, tiny maps)
+__global__ __launch_bounds__(256) void range_guard_snapshot(SnapArgs snap) {
+    snapshot_inputs_if_range_fails(snap, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // Split-K fix-up (forward.hip: small batches): out[m][n] = stored(relu(part[m][0][n] + part[m][1][n] + ...)) in the f16x3

@@ -181,6 +181,11 @@ class Engine:
         self._check(self._L.davo_range_stats(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return {"recalibrations": a.value, "f32_batches": b.value, "reissued": c.value}
 
+    def range_report(self):
+        """What the range management last did, in words ('' if nothing): the verdict behind a re-calibration or a float32
+        batch, or the weight tensor whose per-input-channel spread keeps the network on the float32 kernels."""
+        return (self._L.davo_range_report(self._ctx) or b"").decode()
+
     def set_activation_shifts(self, shifts=None):
         """Install storage scales from an earlier calibrate() (dict or sequence of 6 ints; None = none)."""
         if shifts is None:

@@ -79,12 +79,20 @@ int davo_forward(davo_ctx* ctx, int B, const uint8_t* img, const float* flow, co
  * which case it is bracketed by HIP events, synchronised, and the device time is returned.
  * With davo_set_inflight(ctx, n > 1) the timed form still waits for its own batch only and the
  * batches of all slots are judged together at davo_synchronize().
- * f16x3 range guard: the asynchronous form cannot know its own result, so the batches issued
- * since the last davo_synchronize() get their verdict there.  A failed verdict RE-ISSUES those
- * batches (see "auto_range" below), so the caller must keep the input and output buffers of every
- * batch alive and unchanged until davo_synchronize() has returned — which it has to anyway to
- * read the poses.  The timed, synchronous form judges (and re-issues) its own batch; elapsed_ms is
- * then the first issue's time. */
+ * f16x3 range guard: the asynchronous form cannot know its own result, so every batch gets a range record of its own
+ * and is judged later: when its slot of a ring of 4 is needed again (four batches on), at davo_synchronize(), or before
+ * anything that changes the storage scales.  A failed verdict RE-ISSUES that batch (see "auto_range" below) and
+ * rewrites its pose buffer, so:
+ *   - the OUTPUT buffer of a batch must stay alive until davo_synchronize() has returned, and its poses are final only
+ *     then (davo_range_stats / davo_range_report say whether anything was re-issued);
+ *   - the INPUT buffers (16-byte aligned) may be overwritten or recycled as soon as work ordered behind the call on
+ *     the context's stream may run (e.g. the next H2D on that stream, or anything behind an event recorded there):
+ *     the batch's last kernel sees the finished range record and, if the batch will have to be re-issued, copies
+ *     the inputs it was issued on into buffers of the context (1.97 MB per 128x416 window, four batches deep,
+ *     allocated at the first such call); the re-issue reads that copy.  A batch in range - every batch of a
+ *     well-ranged checkpoint - copies nothing.  A caller that keeps its inputs unchanged until davo_synchronize()
+ *     anyway can save the buffers with davo_set_option(ctx, "stable_inputs", 1); re-issues then read the caller's.
+ * The timed, synchronous form judges (and re-issues) its own batch; elapsed_ms is then the first issue's time. */
 int davo_forward_device(davo_ctx* ctx, int B, const void* d_img, const void* d_flow,
                         const void* d_seg, void* d_pose, float* elapsed_ms);
 
@@ -106,12 +114,11 @@ int davo_host_register(int device, void* p, size_t bytes);
 int davo_host_unregister(void* p);
 int davo_memcpy_h2d(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
 int davo_memcpy_d2h(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
-/* Waits for every stream of the context, then gives the f16x3 batches issued through
- * davo_forward_device since the previous call their range verdict.  If one of them left the fp16-pair
- * storage range, all of them are re-issued before the call returns (re-calibrated, or on the float32
- * kernels: "auto_range"), so on DAVO_OK every pose buffer holds float32-grade results.  With
- * "auto_range" 0 the failed verdict is returned as DAVO_ERR_RANGE instead (the poses of those batches are
- * not float32-grade; the next batch starts a fresh record). */
+/* Gives every f16x3 batch issued through davo_forward_device and not judged yet its range verdict (each on its own
+ * record), then waits for every stream of the context.  A batch that left the fp16-pair storage range is re-issued
+ * before the call returns (re-calibrated, or on the float32 kernels: "auto_range"), so on DAVO_OK every pose buffer
+ * holds float32-grade results.  With "auto_range" 0 the first failed verdict is returned as DAVO_ERR_RANGE instead
+ * (the poses of that batch are not float32-grade; all batches have been judged, nothing stays pending). */
 int davo_synchronize(davo_ctx* ctx);
 /* Run on a caller-owned hipStream_t (NULL restores the context's own stream). */
 int davo_set_stream(davo_ctx* ctx, void* hip_stream);
@@ -174,10 +181,16 @@ int davo_set_activation_shifts(davo_ctx* ctx, const int* shifts);
 /* Range recoveries since davo_create: re-calibrations triggered by a failed verdict, batches that ran on the float32
  * kernels because no scale covered them, batches re-issued in total.  Any pointer may be NULL. */
 int davo_range_stats(davo_ctx* ctx, long long* recalibrations, long long* f32_batches, long long* reissued);
+/* What the range management last did, in words ("" if nothing yet): which layer's verdict triggered a re-calibration or
+ * a float32 batch, or which weight tensor's per-input-channel spread keeps the network on the float32 kernels.  The
+ * string lives until the next call on the context. */
+const char* davo_range_report(const davo_ctx* ctx);
 
 /* Options.
  *   "auto_range" (default 1): f16x3 batches that leave the fp16-pair storage range are re-issued (see above); 0 = the
  *       failed verdict is returned as DAVO_ERR_RANGE.
+ *   "stable_inputs" (default 0): 1 = the caller keeps the input buffers of every davo_forward_device batch unchanged
+ *       until davo_synchronize(); the library then takes no copies of them (see davo_forward_device).
  * Kernel-fusion switches of the f16x3 path (both modes give the same poses to ~1e-7):
  *   "fuse_pose" (default 1): pred 1x1 + spatial mean + 0.01 (nets/posenn.py:240-250) run in cnv7's
  *       epilogue; the cnv7 activation is never written to HBM.  0 = cnv7 stored, separate pose-head kernels.

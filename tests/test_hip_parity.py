@@ -957,12 +957,72 @@ def test_auto_range_device_path_reissues_at_synchronize(c_oracle):
     for k in range(2):
         assert_pose_close(sets[k][3].download((B, 2, 6)), wants[k], "device path, set %d" % k)
     st = e.range_stats()
-    assert st["reissued"] == 2 and st["recalibrations"] >= 1 and st["f32_batches"] == 0, st     # two distinct batches, each once
+    assert st["reissued"] == 3 and st["recalibrations"] >= 1 and st["f32_batches"] == 0, st     # every issued batch once, on its own record
+    assert "re-calibrated" in e.range_report() and "cnv3" in e.range_report(), e.range_report()
     for k in (0, 1):
         e.forward_device(B, *sets[k])
     e.synchronize()
     assert e.range_stats() == st
     assert e.forward_device(B, *sets[0], timed=True) > 0.0
+    e.close()
+
+
+def test_streaming_caller_recycles_its_input_buffers_before_the_verdict(c_oracle):
+    """A double-buffered H2D loop (the shape of a streaming caller): ONE set of input buffers, overwritten with the next
+    batch's data - stream-ordered, behind the forward that read them - long before davo_synchronize.  With a checkpoint that
+    trips the range guard every batch is re-issued at its verdict: from the context's own copy of what was issued, so every
+    batch's poses are oracle-grade although the caller's buffers hold later data by then (round 3 re-issued from the caller's
+    pointers: VERDICT r3 item 4).  Six batches: more than the ring of four, so slots are judged and reused while issuing."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B, n = 2, 6
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, 64, 96, B, _rescaled(weights, 16), "f16x3")
+    data = [synth.make_inputs(B, 64, 96, first_window=3 * k) for k in range(n)]
+    wants = [c_oracle.forward(cfg, *d, weights) for d in data]
+    d_img, d_flow, d_seg = e.alloc(data[0][0].nbytes), e.alloc(data[0][1].nbytes), e.alloc(data[0][2].nbytes)
+    poses = [e.alloc(B * 48) for _ in range(n)]
+    for k in range(n):
+        d_img.upload(data[k][0]); d_flow.upload(data[k][1]); d_seg.upload(data[k][2])      # on the context's stream, behind batch k - 1
+        e.forward_device(B, d_img, d_flow, d_seg, poses[k])
+    poison = np.full_like(data[0][0], 255)
+    d_img.upload(poison)                                                   # and the buffers do not even hold the last batch any more
+    e.synchronize()
+    for k in range(n):
+        assert_pose_close(poses[k].download((B, 2, 6)), wants[k], "recycled inputs, batch %d" % k)
+    st = e.range_stats()
+    # batches 0..3 went out on the old scales; issuing batch 4 needed batch 0's ring slot, so batch 0 was judged and the scales
+    # re-calibrated there: batches 4 and 5 were in range from the start
+    assert st["reissued"] == 4 and st["recalibrations"] >= 1 and st["f32_batches"] == 0, st
+    # once the scales hold, the same loop re-issues nothing
+    for k in range(n):
+        d_img.upload(data[k][0]); d_flow.upload(data[k][1]); d_seg.upload(data[k][2])
+        e.forward_device(B, d_img, d_flow, d_seg, poses[k])
+    e.synchronize()
+    assert e.range_stats() == st
+    for k in range(n):
+        assert_pose_close(poses[k].download((B, 2, 6)), wants[k], "recycled inputs, scales settled, batch %d" % k)
+    e.close()
+
+
+def test_stable_inputs_reissue_from_the_callers_buffers(c_oracle):
+    """"stable_inputs" 1: the caller promises unchanged inputs until the verdict, the library takes no copies and a re-issue
+    reads the caller's buffers (the round-3 behaviour, now opt-in)."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B = 2
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, 64, 96, B, _rescaled(weights, 16), "f16x3")
+    e.set_option("stable_inputs", 1)
+    sets, wants = [], []
+    for k in range(3):
+        img, flow, seg = synth.make_inputs(B, 64, 96, first_window=4 * k)
+        sets.append((e.alloc(img.nbytes).upload(img), e.alloc(flow.nbytes).upload(flow), e.alloc(seg.nbytes).upload(seg), e.alloc(B * 48)))
+        wants.append(c_oracle.forward(cfg, img, flow, seg, weights))
+    for k in (0, 1, 2, 0, 1, 2):
+        e.forward_device(B, *sets[k])
+    e.synchronize()
+    for k in range(3):
+        assert_pose_close(sets[k][3].download((B, 2, 6)), wants[k], "stable inputs, set %d" % k)
+    assert e.range_stats()["reissued"] == 6
     e.close()
 
 
