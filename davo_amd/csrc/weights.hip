@@ -5,6 +5,7 @@
 //               pre-multiplied by a power of two so the fp16 residuals of small weights stay normal
 // rotation/cnv6 and translation/cnv6 are stacked along N (one GEMM, both read cnv5:
 // nets/posenn.py:222-238); cnv7 is one group per head.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -345,14 +346,27 @@ int build_packed_weights_h3(davo_ctx* c) {
                 const std::string name = k < 4 ? std::string(lw[k]) : std::string("pose_exp_net/pose/") + heads[h] + lw[k];
                 const HostTensor& t = W(name);
                 const int64_t taps = t.shape[0] * t.shape[1], cin = t.shape[2], cout = t.shape[3];
-                float mx = 0.f, mn = 3.4e38f;
+                // Upward spread only (round 4): what matters is a channel whose weights are 2^r LARGER than the typical channel's (its
+                // small activations then carry the output).  A dead or pruned channel with tiny weights is harmless - its lost
+                // low bits are multiplied by nothing - so the reference point is the lower quartile of the per-channel norms,
+                // not their minimum: up to a quarter of the channels may be arbitrarily small without moving it.
+                std::vector<float> norms;
                 for (int64_t ci = 0; ci < cin; ++ci) {
                     float m = 0.f;
                     for (int64_t tp = 0; tp < taps; ++tp)
                         for (int64_t co = 0; co < cout; ++co) m = std::fmax(m, std::fabs(t.data[(tp * cin + ci) * cout + co]));
-                    if (m > 0.f && std::isfinite(m)) { mx = std::fmax(mx, m); mn = std::fmin(mn, m); }
+                    if (std::isfinite(m)) norms.push_back(m);
                 }
-                if (mx > 0.f && mn > 0.f) {
+                if (norms.empty()) continue;
+                std::sort(norms.begin(), norms.end());
+                const float mx = norms.back(), typical = norms[norms.size() / 4];
+                if (mx > 0.f && typical > 0.f) {
+                    int e1, e0;
+                    (void)frexpf(mx, &e1); (void)frexpf(typical, &e0);
+                    if (e1 - e0 > c->weight_channel_spread_log2) { c->weight_channel_spread_log2 = e1 - e0; c->weight_channel_spread_layer = name; }
+                } else if (mx > 0.f) {          // more than a quarter of the channels are all-zero: compare with the smallest non-zero norm
+                    float mn = mx;
+                    for (float m : norms) if (m > 0.f) { mn = m; break; }
                     int e1, e0;
                     (void)frexpf(mx, &e1); (void)frexpf(mn, &e0);
                     if (e1 - e0 > c->weight_channel_spread_log2) { c->weight_channel_spread_log2 = e1 - e0; c->weight_channel_spread_layer = name; }

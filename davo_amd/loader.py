@@ -220,6 +220,36 @@ class ThreadedWindowLoader:
 _W = {}                              # per worker process: the attached buffer ring and the dump it reads
 
 
+def worker_context():
+    """The multiprocessing context the loader's workers are started from: a FORK SERVER that has this module, numpy and Pillow
+    imported already, so a worker is a fork of a warm interpreter (a few ms) instead of a spawned one that imports them
+    (~0.3-0.5 s each, twelve at once).  The server itself is a spawned process that never touches a GPU, so forking it is safe
+    whatever the parent holds (a HIP context must not be forked); call ``warm_workers()`` as early as possible - before the
+    parent's own heavy imports and its GPU set-up - and the server's imports pass behind them."""
+    import multiprocessing as mp
+    ctx = mp.get_context("forkserver")
+    ctx.set_forkserver_preload(["davo_amd.loader", "numpy", "PIL.Image", "PIL.JpegImagePlugin"])
+    return ctx
+
+
+def warm_workers():
+    """Start the fork server now (idempotent, returns at once: its imports run in the server process)."""
+    worker_context()
+    from multiprocessing import forkserver
+    forkserver.ensure_running()
+
+
+def shm_budget_bytes():
+    """Bytes of shared, page-locked batch buffers a loader may create: a quarter of what /dev/shm has free, at most 2 GiB
+    (containers often mount 64 MB there: the first touch of a larger segment is a SIGBUS, not an exception)."""
+    try:
+        st = os.statvfs("/dev/shm")
+        free = st.f_bavail * st.f_frsize
+    except OSError:
+        return 0
+    return int(min(free // 4, 2 << 30))
+
+
 def _proc_init(names, B, H, W, dump_dir, seq, flow_planes, seg_planes):
     from multiprocessing import shared_memory
     ring = []
@@ -233,6 +263,10 @@ def _proc_init(names, B, H, W, dump_dir, seq, flow_planes, seg_planes):
     _W.update(ring=ring, dump=dump_dir, seq=seq, H=H, W=W, fp=flow_planes, sp=seg_planes)
 
 
+def _proc_ready():
+    return os.getpid()
+
+
 def _proc_fill(ring_idx, slot0, w0, n):
     """windows w0 .. w0+n-1 (target frames w+1) into slots slot0.. of buffer set ring_idx; returns n"""
     img, flow, seg = _W["ring"][ring_idx][1]
@@ -242,6 +276,10 @@ def _proc_fill(ring_idx, slot0, w0, n):
     return n
 
 
+class ShmBudgetError(RuntimeError):
+    """The shared batch buffers of a ProcessWindowLoader do not fit /dev/shm (see shm_budget_bytes)."""
+
+
 class ProcessWindowLoader:
     """Batches of windows [lo, hi) in order, filled by ``procs`` worker PROCESSES that decode the strip and read the
     .npy planes of whole windows straight into shared-memory batch buffers (data_loader.py:241-325's pipeline with
@@ -249,19 +287,33 @@ class ProcessWindowLoader:
     The parent never touches a pixel: it hands out (buffer set, slot range, window range) tasks of ``chunk`` windows
     and yields a batch when its tasks are done.  ``pin(array)`` / ``unpin(array)`` page-lock the buffers for the H2D DMA
     (davo_amd.pin_array: hipHostRegister over the shared mapping).  Only the flow planes and label maps the variant
-    consumes are read; the rest of a slot keeps its zeros.  Start method "spawn": the parent may hold a HIP context.
+    consumes are read; the rest of a slot keeps its zeros.  Workers are forks of a warm fork server (worker_context): the
+    parent may hold a HIP context, the server never does.
 
     A batch is valid until the consumer asks for the next one; the last one until ``close()`` (or the loader's deletion),
     which unpins and unmaps the buffers.  The end of iteration stops the workers and removes the segments' names."""
 
     def __init__(self, dump_dir, seq, H, W, lo, hi, batch_size, procs=8, prefetch=2, chunk=None, pin=None, unpin=None,
-                 flow_planes=FLOW_PLANES_USED, seg_planes=SEG_PLANES_SOURCES):
+                 flow_planes=FLOW_PLANES_USED, seg_planes=SEG_PLANES_SOURCES, shm_budget=None):
         self.args = (dump_dir, seq, H, W)
         self.lo, self.hi, self.B = lo, hi, batch_size
         self.procs, self.prefetch = max(1, procs), max(1, prefetch)
         self.chunk = chunk or max(1, min(4, batch_size))
         # batches being filled at once: enough windows in flight (three tasks per worker) that no worker idles at a batch's end
         self.fill = max(2, -(-3 * self.procs * self.chunk // batch_size))
+        # the ring is sized in BYTES: prefetch + fill + 2 batch buffer trios if they fit the budget (shm_budget_bytes), fewer
+        # batches in flight if not, and a clear error - the caller falls back to the threaded loader - if not even three fit
+        per_batch = batch_size * (H * 3 * W * 3 + 4 * H * W * 2 * 4 + 3 * H * W * 4)
+        budget = shm_budget_bytes() if shm_budget is None else shm_budget
+        want = self.prefetch + self.fill + 2
+        self.nring = min(want, budget // per_batch)
+        if self.nring < 4:            # one being filled, one queued, one waiting in q.put, one with the consumer
+            raise ShmBudgetError("batch buffers of %.0f MB each do not fit /dev/shm's budget of %.0f MB four times "
+                                 "(ProcessWindowLoader needs shared memory: use the threaded loader, --loader_procs 0)"
+                                 % (per_batch / 2 ** 20, budget / 2 ** 20))
+        if self.nring < want:
+            self.fill = max(1, self.nring - 3)
+            self.prefetch = self.nring - 2 - self.fill
         self.pin, self.unpin, self.fp, self.sp = pin, unpin, flow_planes, seg_planes
         self._segs, self._views, self._pool, self._pinned, self._unlinked = [], [], None, [], []
         self._thread = self._q = self._stop_evt = None
@@ -271,11 +323,9 @@ class ProcessWindowLoader:
 
     def _open(self):
         self.close()                                      # a second iteration starts from fresh buffers
-        import multiprocessing as mp
         from multiprocessing import shared_memory
         dump_dir, seq, H, W = self.args
         B = self.B
-        self.nring = self.prefetch + self.fill + 2
         sizes = (B * H * 3 * W * 3, B * 4 * H * W * 2 * 4, B * 3 * H * W * 4)
         for _ in range(self.nring):
             trio = [shared_memory.SharedMemory(create=True, size=max(n, 1)) for n in sizes]
@@ -289,8 +339,12 @@ class ProcessWindowLoader:
                     self.pin(v)
                     self._pinned.append(v)
         names = [[sm.name for sm in trio] for trio in self._segs]
-        self._pool = ProcessPoolExecutor(self.procs, mp_context=mp.get_context("spawn"), initializer=_proc_init,
+        self._pool = ProcessPoolExecutor(self.procs, mp_context=worker_context(), initializer=_proc_init,
                                          initargs=(names, B, H, W, dump_dir, seq, self.fp, self.sp))
+        # ProcessPoolExecutor starts its workers lazily, one per submitted task: ask for all of them now, so that they fork
+        # (and attach the buffers) while the caller is still setting up
+        for f in [self._pool.submit(_proc_ready) for _ in range(self.procs)]:
+            f.add_done_callback(lambda _f: None)
 
     def _stop(self):
         """end of iteration: no more tasks; the names leave /dev/shm (nothing leaks if the process dies from here on) while

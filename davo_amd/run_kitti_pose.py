@@ -48,10 +48,12 @@ def main(argv=None):
                     help="(threaded loader) extra JPEG decode processes; 0 = decode in the loader threads")
     ap.add_argument("--loader_procs", type=int, default=-1,
                     help="worker processes that decode the strips and read the .npy planes straight into shared, page-locked batch "
-                         "buffers (davo_amd/loader.py: ProcessWindowLoader).  -1 = this rank's CPU share minus two, at most 12; "
+                         "buffers (davo_amd/loader.py: ProcessWindowLoader).  -1 = this rank's CPU share minus two, at most 16; "
                          "0 = the threaded loader (--loader_threads)")
     ap.add_argument("--force_comm", action="store_true",
                     help="build the RCCL communicator and run the pose all-gather at world size 1 too (exercises the multi-GPU path on one GPU)")
+    ap.add_argument("--emulate_shard", default=None, metavar="r/R",
+                    help="measurement aid: do what rank r of R would do (its window shard, the gather, the whole stitch) in this one process")
     ap.add_argument("--report", default=None, help="write the run's time split (load wait / forward / gather / stitch / write) as JSON here")
     a = ap.parse_args(argv)
 
@@ -64,6 +66,12 @@ def main(argv=None):
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     device_index = local_rank
+    emulate = tuple(int(x) for x in a.emulate_shard.split("/")) if a.emulate_shard else None
+    if not a.synthetic and a.loader_procs != 0:
+        # first thing this rank does: the fork server the loader's workers come from starts importing numpy / Pillow now, behind
+        # this process's own imports, the checkpoint read and the GPU set-up (davo_amd/loader.py: worker_context)
+        from .loader import warm_workers
+        warm_workers()
 
     H, W = a.img_height, a.img_width
     if a.synthetic:
@@ -85,7 +93,7 @@ def main(argv=None):
                     cores = min(cores, max(1, int(int(q) / int(period))))
             except (OSError, ValueError):
                 pass
-            procs = max(1, min(12, cores - 2))
+            procs = max(1, min(16, cores - 2))
         from .version import parse_version
         static_all = parse_version(a.version).att_source == "static_all"   # only -segmask_all-static reads the target frame's label map
         load = S.kitti_window_loader(a.concat_img_dir, a.test_seq, n_frames, H, W,
@@ -94,7 +102,7 @@ def main(argv=None):
                                      pin=lambda arr: pin_array(arr, device_index), unpin=unpin_array,
                                      seg_planes=(0, 1, 2) if static_all else None)
         # the loader's workers come up (spawn + imports: ~0.5 s) while the checkpoint is read and the GPU context is built
-        load.prestart(*S.shard_windows(n_frames - 2, world, rank), a.batch_size)
+        load.prestart(*S.shard_windows(n_frames - 2, *((world, rank) if emulate is None else (emulate[1], emulate[0]))), a.batch_size)
         from .tf_checkpoint import load_weights
         weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
 
@@ -109,7 +117,11 @@ def main(argv=None):
     comm = RcclComm.from_env(system.engine) if (world > 1 or a.force_comm) else None      # collective; fails loudly, no other transport
     t0 = time.perf_counter()
     timing = {}
-    traj, poses = S.run_sequence(infer, load, n_frames, a.batch_size, rank, world, comm, timing)
+    # this rank's prefetching loader (started above): handed in ready-made and closed only after the trajectory is written -
+    # unpinning and unmapping ~1 GB of batch buffers takes 0.15 s and used to run inside run_sequence when the last reference died
+    lo_hi = S.shard_windows(n_frames - 2, *((world, rank) if emulate is None else (emulate[1], emulate[0])))
+    ld = load.for_range(*lo_hi, a.batch_size) if hasattr(load, "for_range") else load
+    traj, poses = S.run_sequence(infer, ld, n_frames, a.batch_size, rank, world, comm, timing, emulate)
     dt = time.perf_counter() - t0
     if rank == 0:
         os.makedirs(a.output_dir, exist_ok=True)
@@ -128,6 +140,8 @@ def main(argv=None):
             import json
             with open(a.report, "w") as f:
                 json.dump({k: (round(v, 4) if isinstance(v, float) else v) for k, v in timing.items()}, f)
+    if hasattr(ld, "close"):
+        ld.close()
     if comm is not None:
         comm.barrier()
         comm.close()

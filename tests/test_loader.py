@@ -181,3 +181,52 @@ def test_process_loader_started_early_and_never_iterated_cleans_up(dump):
     fac = S.kitti_window_loader(d, 3, n_windows + 2, H, W, procs=2)
     fac.prestart(0, n_windows, 4)
     assert [(s, e) for s, e, _ in fac.for_range(0, n_windows, 4)] == [(0, 4), (4, 7)]
+
+
+def test_process_loader_sizes_its_ring_in_bytes_and_falls_back_when_shm_is_too_small(dump, capsys):
+    """the shared batch buffers are budgeted against /dev/shm (a quarter of its free space, at most 2 GiB).  A ring
+    that does not fit whole is shortened (fewer batches in flight, same batches out); one that does not fit four buffer sets is
+    refused with a clear error, and the loader factory then decodes with threads into its own buffers instead."""
+    d, n_windows, H, W = dump, 7, 32, 64
+    B = 2
+    per_batch = B * (H * 3 * W * 3 + 4 * H * W * 2 * 4 + 3 * H * W * 4)
+    full = L.ProcessWindowLoader(d, 3, H, W, 0, n_windows, B, procs=2, prefetch=2)
+    assert full.nring == full.prefetch + full.fill + 2 and L.shm_budget_bytes() > 0
+    full.close()
+    small = L.ProcessWindowLoader(d, 3, H, W, 0, n_windows, B, procs=2, prefetch=2, shm_budget=4 * per_batch + 100)
+    assert small.nring == 4 and small.prefetch + small.fill + 2 == 4
+    ref = {w: L.load_window(d, 3, w + 1, H, W) for w in range(n_windows)}
+    got = [(s, e, img.copy()) for s, e, (img, _, _) in small]
+    assert [(s, e) for s, e, _ in got] == [(0, 2), (2, 4), (4, 6), (6, 7)]
+    assert all(np.array_equal(img[i], ref[s + i][0]) for s, e, img in got for i in range(e - s))
+    small.close()
+    with pytest.raises(L.ShmBudgetError, match="do not fit"):
+        L.ProcessWindowLoader(d, 3, H, W, 0, n_windows, B, procs=2, shm_budget=3 * per_batch)
+    # the factory's fallback
+    real = L.shm_budget_bytes
+    L.shm_budget_bytes = lambda: 3 * per_batch
+    try:
+        fac = S.kitti_window_loader(d, 3, n_windows + 2, H, W, procs=2)
+        ld = fac.for_range(0, n_windows, B)
+        assert isinstance(ld, L.ThreadedWindowLoader)
+        assert [(s, e) for s, e, _ in ld] == [(0, 2), (2, 4), (4, 6), (6, 7)]
+        fac.prestart(0, n_windows, B)                                     # nothing to start early: no error either
+    finally:
+        L.shm_budget_bytes = real
+    assert "falling back to the threaded loader" in capsys.readouterr().err
+
+
+def test_emulated_shard_does_one_ranks_work(dump, c_oracle):
+    """run_sequence(emulate=(r, R)): rank r's windows carry the network's poses, the others zero motion."""
+    from davo_amd import parse_version, FLAGSHIP_VERSION
+    d, n_windows, H, W = dump, 7, 32, 64
+    cfg = parse_version(FLAGSHIP_VERSION)
+    weights = synth.make_weights(cfg)
+    infer = lambda img, flow, seg: c_oracle.forward(cfg, img, flow, seg, weights)      # noqa: E731
+    fac = S.kitti_window_loader(d, 3, n_windows + 2, H, W)
+    _, ref = S.run_sequence(infer, fac, n_windows + 2, 2)
+    timing = {}
+    traj, poses = S.run_sequence(infer, fac, n_windows + 2, 2, timing=timing, emulate=(1, 3))
+    lo, hi = S.shard_windows(n_windows, 3, 1)
+    assert (lo, hi) == (3, 6) and timing["windows_this_rank"] == 3 and len(traj) == n_windows + 2
+    assert np.array_equal(poses[lo:hi], ref[lo:hi]) and not poses[:lo].any() and not poses[hi:].any()

@@ -3,7 +3,7 @@
 reference's on-disk format -> CLI (worker-process loader, RCCL all-gather forced at world size 1) -> trajectory, with the run's
 time split.  The dump holds 640 distinct windows; the rest are links to them (same files, same decode work, warm page cache).
 
-    python tools/config4_from_files.py [out.json]"""
+    python tools/config4_from_files.py [out.json] [--shard r/R]      # --shard 3/8: only what rank 3 of 8 would do (568 windows)"""
 import json
 import os
 import sys
@@ -18,7 +18,14 @@ def main():
     import numpy as np
     from davo_amd import loader as L, synth, parse_version, FLAGSHIP_VERSION, run_kitti_pose
     N, real, H, W, B = 4541, 642, 128, 416, 64
-    out = sys.argv[1] if len(sys.argv) > 1 else None
+    argv = sys.argv[1:]
+    shard = argv.pop(argv.index("--shard") + 1) if "--shard" in argv else None
+    if shard:
+        argv.remove("--shard")
+    procs = argv.pop(argv.index("--procs") + 1) if "--procs" in argv else None
+    if procs:
+        argv.remove("--procs")
+    out = argv[0] if argv else None
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         L.write_synthetic_dump(d, 0, real, H, W)
         for w in range(real - 2, N - 2):
@@ -29,13 +36,14 @@ def main():
         for rep in range(3):                                           # run 0 pays the library's first load and the cold page cache
             t0 = time.perf_counter()
             run_kitti_pose.main(["--concat_img_dir", d, "--ckpt_file", os.path.join(d, "w.npz"), "--output_dir", d, "--test_seq", "0",
-                                 "--batch_size", str(B), "--force_comm", "--report", os.path.join(d, "report.json")])
+                                 "--batch_size", str(B), "--force_comm", "--report", os.path.join(d, "report.json")] +
+                                (["--emulate_shard", shard] if shard else []) + (["--loader_procs", procs] if procs else []))
             r = json.load(open(os.path.join(d, "report.json")))
             r["process_wall_s_incl_context_and_weights"] = round(time.perf_counter() - t0, 3)
             runs.append(r)
         assert len(open(os.path.join(d, "00-pred_kitti_pose.txt")).read().splitlines()) == N
     rec = {"what": "BASELINE configs[3] shape on ONE rank from files (seq 00: 4541 frames, 4539 windows, batch 64, forced RCCL gather); "
-                   "8 ranks would each take 568 of these windows", "runs": runs}
+                   "8 ranks would each take 568 of these windows" + (": THIS run is the work of rank %s" % shard if shard else ""), "runs": runs}
     print(json.dumps(rec, indent=1))
     if out:
         json.dump(rec, open(out, "w"), indent=1)
