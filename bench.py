@@ -12,8 +12,8 @@ RCCL all-gather (davo_amd/comm.py), reported separately and not part of `value`.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--settle S] [--batch B] [--height H --width W] [--force-comm]
 
 Untimed before the timed region: W warm-up steps, then S settle steps (default: whatever brings W + S to 100) — the
-chip's clock needs ~25 steps (30 ms) of this load to settle after idle; `settle_steps` is disclosed in the JSON and the
-timed region is exactly K full forwards either way.  `timing` in the JSON shows the ramp that is left: per-step periods
+chip's clock needs ~25 steps (30 ms) of this load to settle after idle.  The JSON's `warmup` is the number of untimed
+steps that really ran (W + S; `warmup_arg` and `settle_steps` beside it) and the timed region is exactly K full forwards.  `timing` in the JSON shows the ramp that is left: per-step periods
 and the dominant launch's durations at the start and at the end of the timed region.
 
 `--gpus N` with N > 1 starts the N ranks itself (davo_amd/launch.py: a parent that touches no GPU and
@@ -314,12 +314,16 @@ def main():
                 eng.alloc(seg.nbytes).upload(np.tile(seg2, (reps2, 1, 1, 1, 1))[:B]), eng.alloc(B * 12 * 4))
         both = [sets[0], set2]
         eng.set_inflight(2)
-        for i in range(4):
+        # the same untimed run-in as the main leg: this leg follows the float32 leg and the per-kernel pass, whose load is another
+        # one (round 3 gave it 4 steps and timed it on the clock ramp: 26.07 k against 26.46 k for one in flight in BENCH_r03,
+        # where an interleaved A/B in one process has two in flight ahead in 10 rounds of 10, +5.5 %: profiles/r04_pipelined_ab.log)
+        for i in range(args.warmup + settle):
             eng.forward_device(B, *both[i % 2])
         pdt = timed(lambda k: [eng.forward_device(B, *both[i % 2]) for i in range(k)], args.steps)
         pipelined = {"batches_in_flight": 2, "value": round(world * B * args.steps / pdt, 2), "unit": "triplets/s",
-                     "ms_per_step": round(pdt / args.steps * 1e3, 4),
-                     "note": "davo_set_inflight(ctx, 2); same K steps, barrier + synchronize on both sides, max over ranks"}
+                     "ms_per_step": round(pdt / args.steps * 1e3, 4), "untimed_steps_before": args.warmup + settle,
+                     "note": "davo_set_inflight(ctx, 2); same K steps, same untimed run-in, barrier + synchronize on both sides, max over "
+                             "ranks; the next batch's small kernels overlap this batch's large convolutions"}
         eng.set_inflight(1)
         eng.forward_device(B, *sets[0])
         eng.synchronize()
@@ -370,7 +374,8 @@ def main():
             "metric": "pose-net triplets/sec (128x416x3-frame)" if (H, W) == (128, 416)
                       else "pose-net triplets/sec (%dx%dx3-frame)" % (H, W),
             "value": round(value, 2), "unit": "triplets/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
+            "warmup": args.warmup + settle, "warmup_arg": args.warmup, "settle_steps": settle,
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic (splitmix64 seed 8964; random-init He-uniform weights; no KITTI/ckpt offline)",
             "config": {"workload": workload_name(B, H, W, world),

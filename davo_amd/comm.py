@@ -68,6 +68,25 @@ def _launcher_start_time():
         return 0.0
 
 
+def _own_start_time():
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/stat") as f:
+            btime = next(int(l.split()[1]) for l in f if l.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK") - 1.0
+    except (OSError, ValueError, StopIteration, IndexError):
+        return 0.0
+
+
+def id_not_before():
+    """Oldest mtime an id file may have: not older than the launcher process, and never more than a minute older than this
+    rank itself.  The second bound matters when the 'launcher' is a long-lived shell or scheduler step (ranks started by hand
+    with DAVO_COMM_FILE): a file left by a crashed earlier run is younger than that shell but not than this rank."""
+    own = _own_start_time()
+    return max(_launcher_start_time(), own - 60.0 if own > 0 else 0.0)
+
+
 def world_from_env():
     """(rank, local_rank, world) as the launch contract sets them (RANK / LOCAL_RANK / WORLD_SIZE)."""
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,7 +109,7 @@ def publish_id(path, ident):
 def wait_for_id(path, rank, timeout=180.0, not_before=None):
     """ranks > 0: the id rank 0 published under THIS launcher (own uid, complete, not older than the launcher process)"""
     t0 = time.time()
-    not_before = _launcher_start_time() if not_before is None else not_before
+    not_before = id_not_before() if not_before is None else not_before
     while True:
         try:
             st = os.stat(path)

@@ -24,6 +24,14 @@ import tempfile
 import time
 
 
+_BIND_AND_EXEC = ("import os, sys\n"
+                  "try:\n"
+                  "    os.sched_setaffinity(0, {int(c) for c in sys.argv[1].split(',')})\n"
+                  "except OSError:\n"
+                  "    pass\n"
+                  "os.execv(sys.argv[2], sys.argv[2:])\n")
+
+
 def cpu_slices(nprocs, cpus=None):
     """the allowed CPUs cut into nprocs contiguous slices (rank r gets slice r); fewer CPUs than ranks: everyone keeps all"""
     cpus = sorted(os.sched_getaffinity(0) if cpus is None else cpus)
@@ -48,13 +56,13 @@ def spawn_ranks(argv, nprocs, env_extra=None, timeout=None, bind_cpus=True, stdo
             env.setdefault("MASTER_ADDR", "127.0.0.1")
             if env_extra:
                 env.update(env_extra)
-            p = subprocess.Popen([sys.executable] + list(argv), env=env, stdout=stdout)
+            cmd = [sys.executable] + list(argv)
             if slices is not None:
-                try:
-                    os.sched_setaffinity(p.pid, slices[r])  # before the rank has started any thread of its own
-                except OSError:
-                    pass
-            procs.append(p)
+                # the rank binds ITSELF, in a bare interpreter that has imported nothing and started no thread, and then becomes
+                # the real command (exec before anything touches a GPU): every thread the rank ever starts inherits the slice.
+                # (Setting the affinity of p.pid from here after Popen raced with the child's first threads: ADVICE r3.)
+                cmd = [sys.executable, "-c", _BIND_AND_EXEC, ",".join(str(c) for c in sorted(slices[r]))] + cmd
+            procs.append(subprocess.Popen(cmd, env=env, stdout=stdout))
         t0 = time.time()
         code = 0
         live = list(procs)

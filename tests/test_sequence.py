@@ -286,6 +286,14 @@ def test_comm_id_file_from_before_the_launcher_is_stale(tmp_path):
     f.write_bytes(b"x" * 128)
     os.utime(f, (t - 5, t - 5))
     assert os.stat(f).st_mtime < t                           # what RcclComm's reader loop compares
+    # a long-lived launcher (a shell the ranks are started from by hand): a leftover of a crashed earlier run is younger than
+    # the shell, so the age test is also bounded by this rank's own start (minus a minute for rank 0 to have come up first)
+    own = comm._own_start_time()
+    nb = comm.id_not_before()
+    assert 0 < own <= time.time() and nb >= t and nb >= own - 60.0
+    os.utime(f, (own - 3600, own - 3600))
+    with pytest.raises(comm.CommError, match="no RCCL id"):
+        comm.wait_for_id(str(f), 1, timeout=0.2, not_before=max(t - 7200, own - 60.0))      # the launcher is "old": only the second bound holds
 
 
 def test_bench_names_the_config_its_arguments_select():
