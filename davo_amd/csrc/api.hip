@@ -96,8 +96,8 @@ int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const d
     activate_slot(c, 0);
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_zeros), 256));
     HIP_TRY(c, hipMemset(c->d_zeros, 0, 256));
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_range_base), (1 + RANGE_RING) * 8 * sizeof(unsigned)));
-    HIP_TRY(c, hipMemset(c->d_range_base, 0, (1 + RANGE_RING) * 8 * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_range_base), (1 + RANGE_RING) * RANGE_WORDS * sizeof(unsigned)));
+    HIP_TRY(c, hipMemset(c->d_range_base, 0, (1 + RANGE_RING) * RANGE_WORDS * sizeof(unsigned)));
     c->d_range = c->d_range_base;
     return DAVO_OK;
 }
@@ -164,8 +164,9 @@ size_t seg_bytes(const davo_ctx* c) { return (size_t)c->H * c->W * 3 * sizeof(fl
 int ensure_ring(davo_ctx* c, bool snapshots) {
     if (!c->read_stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->read_stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_range), 8 * sizeof(unsigned), hipHostMallocDefault));
-        for (int r = 0; r < RING; ++r) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[r], hipEventDisableTiming));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_range), (1 + RANGE_RING) * RANGE_WORDS * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_range_dev), c->h_range, 0));
+        memset(c->h_range, 0, (1 + RANGE_RING) * RANGE_WORDS * sizeof(unsigned));
     }
     if (snapshots && !c->snap_img[0]) {
         for (int r = 0; r < RING; ++r) {
@@ -177,14 +178,16 @@ int ensure_ring(davo_ctx* c, bool snapshots) {
     return DAVO_OK;
 }
 
-// a record -> host, on a stream of its own (never behind queued batches, never through the null stream); raw[7] = copy taken
-int read_record(davo_ctx* c, const unsigned* d_rec, unsigned raw[8]) {
+// a record -> host, on a stream of its own (never behind queued batches, never through the null stream)
+int read_record(davo_ctx* c, const unsigned* d_rec, unsigned raw[RANGE_WORDS]) {
     if (!c->read_stream) { int rc = ensure_ring(c, false); if (rc) return rc; }
-    HIP_TRY(c, hipMemcpyAsync(c->h_range, d_rec, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, c->read_stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_range, d_rec, RANGE_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, c->read_stream));
     HIP_TRY(c, hipStreamSynchronize(c->read_stream));
-    memcpy(raw, c->h_range, 8 * sizeof(unsigned));
+    memcpy(raw, c->h_range, RANGE_WORDS * sizeof(unsigned));
     return DAVO_OK;
 }
+
+unsigned* ring_record(davo_ctx* c, int r) { return c->d_range_base + RANGE_WORDS * (1 + r); }
 
 void note_seen(davo_ctx* c, const unsigned raw[6], const int* shifts) {
     for (int i = 0; i < 6; ++i) {
@@ -196,7 +199,19 @@ void note_seen(davo_ctx* c, const unsigned raw[6], const int* shifts) {
 }
 
 int zero_base_record(davo_ctx* c, hipStream_t s) {
-    HIP_TRY(c, hipMemsetAsync(c->d_range_base, 0, 8 * sizeof(unsigned), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_range_base, 0, RANGE_WORDS * sizeof(unsigned), s));
+    return DAVO_OK;
+}
+
+// Every stream idle.  The ring's running maxima (params.h) are about to lose their meaning - a failed verdict, or the scales are
+// going to change: read the record of every batch that is still waiting for its verdict into its ticket first, then reset the ring.
+int freeze_pending_and_reset_ring(davo_ctx* c) {
+    for (Ticket& t : c->tickets)
+        if (!t.frozen) {
+            memcpy(t.raw, c->h_range + RANGE_WORDS * (1 + t.ring), sizeof t.raw);      // every stream is idle: the mirrors are final
+            t.frozen = true;
+        }
+    HIP_TRY(c, hipMemset(c->d_range_base + RANGE_WORDS, 0, RANGE_RING * RANGE_WORDS * sizeof(unsigned)));
     return DAVO_OK;
 }
 
@@ -214,7 +229,7 @@ int calibrate_on(davo_ctx* c, int B, const void* d_img, const void* d_flow, cons
         rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
         if (rc) break;
         if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, DAVO_ERR_HIP, "hipStreamSynchronize failed"); break; }
-        unsigned raw[8];
+        unsigned raw[RANGE_WORDS];
         if ((rc = read_record(c, c->d_range_base, raw))) break;
         bool changed = false;
         for (int i = 0; i < 6; ++i) {
@@ -242,7 +257,7 @@ int run_judged(davo_ctx* c, const Ticket& b) {
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->last_precision != 1) return DAVO_OK;
-    unsigned raw[8];
+    unsigned raw[RANGE_WORDS];
     if ((rc = read_record(c, c->d_range_base, raw))) return rc;
     rc = check_range(c, raw);
     if (rc == DAVO_OK) note_seen(c, raw, c->act_shift);
@@ -255,6 +270,7 @@ int run_judged(davo_ctx* c, const Ticket& b) {
 int recover_batch(davo_ctx* c, const Ticket& b) {
     { int rc = sync_all_slots(c); if (rc) return rc; }
     const std::string verdict = c->err;
+    { int rc = freeze_pending_and_reset_ring(c); if (rc) return rc; }       // the failed slot's maximum must go; the scales may move
     activate_slot(c, 0);
     int rc = run_judged(c, b);
     if (rc == DAVO_ERR_RANGE) {
@@ -282,16 +298,41 @@ int recover_batch(davo_ctx* c, const Ticket& b) {
 int judge_front(davo_ctx* c) {
     const Ticket t = c->tickets.front();
     c->tickets.pop_front();
-    HIP_TRY(c, hipEventSynchronize(c->ev_done[t.ring]));
-    unsigned raw[8];
-    int rc = read_record(c, c->d_range_base + 8 * (1 + t.ring), raw);
+    unsigned raw[RANGE_WORDS];
+    int rc = DAVO_OK;
+    if (t.frozen) memcpy(raw, t.raw, sizeof raw);        // read when the ring was reset (every stream was idle then)
+    else {
+        // the batch's last kernel writes its sequence number into the slot's host mirror behind the maxima (prologue.h): poll that,
+        // with the stream's own state as the way out if the device has failed
+        volatile const unsigned* m = c->h_range + RANGE_WORDS * (1 + t.ring);
+        for (unsigned spin = 0; m[RANGE_SEQ] != t.seq; ++spin) {
+            if ((spin & 1023u) == 1023u) {
+                const hipError_t q = hipStreamQuery(t.stream);
+                if (q == hipSuccess) {                                    // the stream is idle: the store is on its way or the kernel never ran
+                    if (m[RANGE_SEQ] == t.seq) break;
+                    HIP_TRY(c, hipStreamSynchronize(t.stream));
+                    if (m[RANGE_SEQ] != t.seq) return fail(c, DAVO_ERR_HIP, "a batch finished without reporting its range record");
+                    break;
+                }
+                if (q != hipErrorNotReady) return fail(c, DAVO_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        for (int i = 0; i < RANGE_WORDS; ++i) raw[i] = m[i];
+    }
     if (rc == DAVO_OK) {
         rc = check_range(c, raw, t.shifts);
         if (rc == DAVO_OK) note_seen(c, raw, t.shifts);
         else if (rc == DAVO_ERR_RANGE && c->opt_auto_range) {
             // the batch's last kernel reached the same verdict on the same record and kept the inputs (prologue.h)
-            if (t.snap && raw[7] != 1u) rc = fail(c, DAVO_ERR_INVALID, "internal: a batch failed its range verdict but its inputs were not kept");
+            if (t.snap && raw[RANGE_SNAP] != 1u) rc = fail(c, DAVO_ERR_INVALID, "internal: a batch failed its range verdict but its inputs were not kept");
             else rc = recover_batch(c, t);
+        } else if (rc == DAVO_ERR_RANGE && !t.frozen) {
+            // no recovery ("auto_range" 0): the slot's running maximum has served its verdict - the next batch starts afresh
+            const std::string keep = c->err;
+            if (hipMemsetAsync(ring_record(c, t.ring), 0, RANGE_WORDS * sizeof(unsigned), c->read_stream) != hipSuccess ||
+                hipStreamSynchronize(c->read_stream) != hipSuccess) rc = fail(c, DAVO_ERR_HIP, "resetting a range record failed");
+            else c->err = keep;
         }
     }
     c->ring_busy[t.ring] = false;              // after the re-issue: it read the slot's copy of the inputs
@@ -329,15 +370,16 @@ int ticket_begin(davo_ctx* c, int B, const void* d_img, const void* d_flow, cons
     const int r = c->ring_next;
     *snap = c->opt_auto_range && !c->opt_stable_inputs;
     { int rc = ensure_ring(c, *snap); if (rc) return rc; }
-    c->d_range = c->d_range_base + 8 * (1 + r);
+    c->d_range = ring_record(c, r);
     c->range_zero = true;
-    c->snap = SnapArgs{};
-    if (*snap) {
-        if (((uintptr_t)d_img | (uintptr_t)d_flow | (uintptr_t)d_seg) & 15) return fail(c, DAVO_ERR_INVALID, "device input buffers must be 16-byte aligned");
-        c->snap = SnapArgs{c->d_range, static_cast<const uint8_t*>(d_img), static_cast<const uint8_t*>(d_flow), static_cast<const uint8_t*>(d_seg),
-                           static_cast<uint8_t*>(c->snap_img[r]), static_cast<uint8_t*>(c->snap_flow[r]), static_cast<uint8_t*>(c->snap_seg[r]),
-                           (unsigned)(img_bytes(c) / 16), (unsigned)(flow_bytes(c) / 32), (unsigned)(flow_bytes(c) / 16), (unsigned)(seg_bytes(c) / 16), B};
-    }
+    if (*snap && (((uintptr_t)d_img | (uintptr_t)d_flow | (uintptr_t)d_seg) & 15)) return fail(c, DAVO_ERR_INVALID, "device input buffers must be 16-byte aligned");
+    if (++c->batch_seq == 0) c->batch_seq = 1;
+    c->snap_seq_issued = c->batch_seq;
+    c->snap = SnapArgs{c->d_range, c->h_range_dev + RANGE_WORDS * (1 + r), c->batch_seq,
+                       static_cast<const uint8_t*>(d_img), static_cast<const uint8_t*>(d_flow), static_cast<const uint8_t*>(d_seg),
+                       *snap ? static_cast<uint8_t*>(c->snap_img[r]) : nullptr, *snap ? static_cast<uint8_t*>(c->snap_flow[r]) : nullptr,
+                       *snap ? static_cast<uint8_t*>(c->snap_seg[r]) : nullptr,
+                       (unsigned)(img_bytes(c) / 16), (unsigned)(flow_bytes(c) / 32), (unsigned)(flow_bytes(c) / 16), (unsigned)(seg_bytes(c) / 16), B};
     return DAVO_OK;
 }
 
@@ -349,8 +391,9 @@ int ticket_end(davo_ctx* c, int rc, int B, const void* d_img, const void* d_flow
     if (rc) return rc;
     if (c->f32_fallback) ++c->n_f32_batches;
     if (c->last_precision != 1) return DAVO_OK;                                  // float32 kernels (weight guard): no record, no verdict
-    HIP_TRY(c, hipEventRecord(c->ev_done[r], c->stream));
-    Ticket t{B, snap ? c->snap_img[r] : d_img, snap ? c->snap_flow[r] : d_flow, snap ? c->snap_seg[r] : d_seg, d_pose, r, snap, {}};
+    Ticket t{};
+    t.B = B; t.img = snap ? c->snap_img[r] : d_img; t.flow = snap ? c->snap_flow[r] : d_flow; t.seg = snap ? c->snap_seg[r] : d_seg;
+    t.pose = d_pose; t.ring = r; t.snap = snap; t.seq = c->snap_seq_issued; t.stream = c->stream;
     for (int i = 0; i < 6; ++i) t.shifts[i] = c->act_shift[i];
     c->tickets.push_back(t);
     c->ring_busy[r] = true;
@@ -419,7 +462,7 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
     { int rc = judge_all(c); if (rc) return rc; }               // device-path batches issued before this call
     activate_slot(c, 0);
     c->d_range = c->d_range_base;
-    HIP_TRY(c, hipMemsetAsync(c->d_range_base, 0, 8 * sizeof(unsigned), c->stream));      // one record covers this call's sub-batches
+    HIP_TRY(c, hipMemsetAsync(c->d_range_base, 0, RANGE_WORDS * sizeof(unsigned), c->stream));      // one record covers this call's sub-batches
     // Sub-batches: the copy of chunk i+1 (copy_stream) overlaps the kernels of chunk i (compute stream).
     // Results do not depend on the split (windows are independent; tests/test_hip_parity.py batch invariance).
     // Only flow planes 0 and 1 are read by the path (davo.py:978-982), so only those cross PCIe.
@@ -450,14 +493,14 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
     HIP_TRY(c, hipMemcpyAsync(pose_out, c->s_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->last_precision != 1) return DAVO_OK;
-    unsigned raw[8];
+    unsigned raw[RANGE_WORDS];
     int rc = read_record(c, c->d_range_base, raw);
     if (rc) return rc;
     rc = check_range(c, raw);
     if (rc == DAVO_OK) note_seen(c, raw, c->act_shift);
     if (rc == DAVO_ERR_RANGE && c->opt_auto_range) {
         // the staged copy of the batch is still in HBM: re-issue it whole (recalibrated, or on the float32 kernels)
-        rc = recover_batch(c, Ticket{B, c->s_img, c->s_flow, c->s_seg, c->s_pose, -1, false, {}});
+        rc = recover_batch(c, [&] { Ticket t{}; t.B = B; t.img = c->s_img; t.flow = c->s_flow; t.seg = c->s_seg; t.pose = c->s_pose; t.ring = -1; t.stream = c->stream; return t; }());
         if (rc == DAVO_OK) HIP_TRY(c, hipMemcpy(pose_out, c->s_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost));
     }
     return rc;
@@ -488,6 +531,7 @@ const char* davo_range_report(const davo_ctx* c) { return c ? c->range_report.c_
 int davo_set_activation_shifts(davo_ctx* c, const int* shifts) {
     if (!c) return DAVO_ERR_INVALID;
     { int rc = judge_all(c); if (rc) return rc; }             // batches issued under the old scales get their verdict first
+    { int rc = freeze_pending_and_reset_ring(c); if (rc) return rc; }      // maxima stored under the old scales say nothing about the new
     for (int i = 0; i < 6; ++i) {
         const int s = shifts ? shifts[i] : 0;
         if (s < -60 || s > 60) return fail(c, DAVO_ERR_INVALID, "activation shift %d outside [-60,60]", s);
@@ -502,6 +546,7 @@ int davo_calibrate(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
     if (!d_img || !d_flow || !d_seg) return fail(c, DAVO_ERR_INVALID, "null device pointer");
     HIP_TRY(c, hipSetDevice(c->device));
     { int rc = judge_all(c); if (rc) return rc; }             // batches issued under the old scales get their verdict first
+    { int rc = freeze_pending_and_reset_ring(c); if (rc) return rc; }
     activate_slot(c, 0);
     float* d_pose = nullptr;
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_pose), (size_t)B * 12 * sizeof(float)));
@@ -530,7 +575,6 @@ void davo_destroy(davo_ctx* c) {
     if (c->read_stream) (void)hipStreamDestroy(c->read_stream);
     if (c->h_range) (void)hipHostFree(c->h_range);
     for (int r = 0; r < RANGE_RING; ++r) {
-        if (c->ev_done[r]) (void)hipEventDestroy(c->ev_done[r]);
         for (void* q : {c->snap_img[r], c->snap_flow[r], c->snap_seg[r]}) if (q) (void)hipFree(q);
     }
     void* misc[] = {c->d_range_base, c->d_splitk, c->d_pose_tiles, c->d_w1patch, c->d_w2patch, c->d_w3patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};

@@ -880,8 +880,7 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
     if (p.y_mode == 1 && p.range) {      // non-negative floats order like their bit patterns; inf = overflow
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-        // one address for the whole launch: only a wave that would raise the record pays for the atomic
-        if (lane == 0 && __float_as_uint(vmax) > __atomic_load_n(p.range, __ATOMIC_RELAXED)) atomicMax(p.range, __float_as_uint(vmax));
+        range_note(p.range, vmax, lane == 0);      // params.h: only a wave that would raise the record pays for the atomic
     }
 }
 

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
     if (p.y_mode == 1 && p.range) {      // non-negative floats order like their bit patterns; inf = overflow
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-        if (lane == 0 && __float_as_uint(vmax) > __atomic_load_n(p.range, __ATOMIC_RELAXED)) atomicMax(p.range, __float_as_uint(vmax));
+        range_note(p.range, vmax, lane == 0);
     }
 }
 

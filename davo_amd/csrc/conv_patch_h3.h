@@ -289,7 +289,7 @@ __global__ __launch_bounds__(cp1::THREADS, 3) void conv_patch_cnv1_h3(ConvPatchP
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
         // one address for the whole launch: only a wave that would raise the record pays for the atomic
-        if (lane == 0 && __float_as_uint(vmax) > __atomic_load_n(p.range, __ATOMIC_RELAXED)) atomicMax(p.range, __float_as_uint(vmax));
+        range_note(p.range, vmax, lane == 0);
     }
 }
 
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(cp2::THREADS, 2) void conv_patch_cnv2_h3(ConvPatchP
     if (p.range) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-        if (lane == 0 && __float_as_uint(vmax) > __atomic_load_n(p.range, __ATOMIC_RELAXED)) atomicMax(p.range, __float_as_uint(vmax));
+        range_note(p.range, vmax, lane == 0);
     }
 }
 
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(cp3::THREADS, 3) void conv_patch_cnv3_h3(ConvPatchP
     if (p.range) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-        if (lane == 0 && __float_as_uint(vmax) > __atomic_load_n(p.range, __ATOMIC_RELAXED)) atomicMax(p.range, __float_as_uint(vmax));
+        range_note(p.range, vmax, lane == 0);
     }
 }
 

@@ -71,13 +71,17 @@ struct Slot {
 // small ring: a range record of its own and - unless the caller declared its inputs stable - room for a context-owned copy of
 // its inputs, which the batch's last kernel fills if (and only if) the record will fail the verdict, so that the re-issue reads
 // exactly what was issued whatever the caller has done to its buffers since (api.hip, prologue.h).
-constexpr int RANGE_RING = 4;
+constexpr int RANGE_RING = 8;
 struct Ticket {
     int B;
     const void *img, *flow, *seg;              // what a re-issue reads: the ring slot's snapshot, or the caller's buffers ("stable_inputs")
     void* pose;
     int ring;
     bool snap;                                 // img / flow / seg are the ring slot's copy
+    bool frozen;                               // raw holds the batch's record (read before the ring's records were reset)
+    unsigned raw[RANGE_WORDS];
+    unsigned seq;                              // the batch's sequence number: its last kernel writes it into the slot's host mirror
+    hipStream_t stream;                        // the stream it was issued on
     int shifts[6];                             // storage scales the batch was issued under (davo_activation_range reports true magnitudes)
 };
 
@@ -147,7 +151,7 @@ struct davo_ctx {
     // f16x3 range management: activations are stored as fp16 pairs scaled by 2^act_shift[layer] (davo_calibrate);
     // every storing epilogue atomicMax-es the largest stored magnitude into d_range[layer]
     int act_shift[7] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned* d_range_base = nullptr;          // [1 + RANGE_RING][8]: record 0 serves the host path, calibration and re-issues; 1.. the ring
+    unsigned* d_range_base = nullptr;          // [1 + RANGE_RING][RANGE_WORDS] (params.h): record 0 serves the host path, calibration and re-issues; 1.. the ring
     unsigned* d_range = nullptr;               // the record the next launches write to (one of the above)
     bool range_zero = false;                   // the next forward's first kernel zeroes that record itself (ticketed device-path batches)
     // Range recovery (davo_set_option "auto_range", default on): every device-path batch is judged on a record of its own, at the
@@ -161,8 +165,9 @@ struct davo_ctx {
     void *snap_img[davo::RANGE_RING] = {}, *snap_flow[davo::RANGE_RING] = {}, *snap_seg[davo::RANGE_RING] = {};
     davo::SnapArgs snap{};                     // set around a ticketed batch: its last kernel copies the inputs if the record fails (prologue.h)
     hipStream_t read_stream = nullptr;
-    hipEvent_t ev_done[davo::RANGE_RING] = {};
-    unsigned* h_range = nullptr;               // page-locked landing pad of a record read
+    unsigned batch_seq = 0, snap_seq_issued = 0;   // sequence number of the last ticketed batch (never 0 for a batch)
+    unsigned* h_range = nullptr;               // page-locked: [0] landing pad of a record read, [1 + r] the mirror ring slot r's last kernel writes
+    unsigned* h_range_dev = nullptr;           // ... as the device sees it
     float range_seen[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // largest true |activation| judged since the last reset
     int sticky_range_rc = 0;                   // "auto_range" 0: a failed verdict met while issuing is reported by the next davo_synchronize
     std::string sticky_range_err;
@@ -251,7 +256,7 @@ inline void split_f16(float v, _Float16* hi, _Float16* lo) {
 void activate_slot(davo_ctx* c, int i);
 int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, void* d_pose);
 // f16x3: verdict on the range record (d_range) read back from the device; DAVO_ERR_RANGE names the layer
-int check_range(davo_ctx* c, const unsigned raw[6], const int* shifts = nullptr);
+int check_range(davo_ctx* c, const unsigned* raw /*[RANGE_WORDS]*/, const int* shifts = nullptr);
 
 // ---- comm.hip -------------------------------------------------------------------------------
 void comm_release(davo_ctx* c);

@@ -90,14 +90,14 @@ void activate_slot(davo_ctx* c, int i) {
 // f16x3 only.  Stored activations (fp16 hi/lo pairs) are float32-grade while the layer's largest stored value is
 // below the fp16 maximum (above it values were clamped) and not so small that the pairs lose their low bits
 // (tools/exp_activation_scale.py: the 1e-4 bar holds down to ~2^-16 of O(1) activations; 2^-11 is the guard).
-int check_range(davo_ctx* c, const unsigned raw[6], const int* shifts) {
+int check_range(davo_ctx* c, const unsigned* raw, const int* shifts) {
     static const char* names[6] = {"cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6"};
     if (!shifts) shifts = c->act_shift;              // the scales the judged batch was issued under
     for (int i = 0; i < 6; ++i) {
         float v;
         memcpy(&v, &raw[i], sizeof v);
+        if (!range_value_fails(v)) continue;         // params.h: the test the batch's last kernel applies too
         const float actual = ldexpf(v, -shifts[i]);
-        if (!range_value_fails(v)) continue;         // params.h: the same test the batch's last kernel applies (prologue.h)
         if (!(v < 65504.f))
             return fail(c, DAVO_ERR_RANGE, "%s activations reach %.4g: outside the fp16-pair storage range at scale 2^%d "
                         "(values were clamped) - run davo_calibrate() or davo_set_precision(ctx, 0)", names[i], (double)actual, shifts[i]);

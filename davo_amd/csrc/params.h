@@ -1,6 +1,6 @@
 // params.h — kernel parameter blocks, tile geometry and constants shared by the kernels
 // (conv_igemm.h, conv_igemm_h3.h, conv_patch_h3.h, prologue.h) and the host code that plans and
-// launches them.  No device code here, so host-only translation units include it cheaply.
+// launches them.  No kernels here (two small inline helpers of the range guard apart), so host-only translation units include it cheaply.
 #pragma once
 #include <stdint.h>
 
@@ -207,15 +207,39 @@ struct ConvPatchParams {
     int dbg;                // measurement only (-DDAVO_TUNING, DAVO_PDBG): 1 = every patch load reads the zero line, 2 = no stores
 };
 
-// ---- f16x3 range guard: the verdict on a batch's record, shared by the host (forward.hip: check_range) and by the kernel
-// that keeps a copy of the batch's inputs when - and only when - that verdict will fail (prologue.h) ------------------------
-__host__ __device__ inline bool range_value_fails(float v) {
-    return !(v < 65504.f) || (v > 0.f && v < 0x1p-11f);        // clamped / inf / NaN, or too small for the fp16 pairs' low halves
+// ---- f16x3 range guard ---------------------------------------------------------------------------------------------------
+// A range record is RANGE_WORDS unsigned words: [layer] = bit pattern of the largest magnitude a storing epilogue of cnv1..cnv6 has
+// written (atomicMax; non-negative floats order like their bit patterns), [RANGE_SNAP] = 1 once a batch's inputs were copied for
+// a re-issue, [RANGE_SEQ] = sequence number of the last batch whose final kernel has seen the record (host mirror only).
+// The maxima are RUNNING maxima over the batches that share a record: zeroed when a verdict failed or the scales changed, not
+// per batch.  Why: a wave only pays for the atomic if it would raise the record, and a record that starts every batch at zero is
+// raised by every wave of the first round - measured at batch 1 with per-batch zeroing: cnv1 8 -> 29 us, cnv5 28 -> 133 us,
+// cnv6 37 -> 141 us (13,000 serialised atomics from the split-K fix-up alone); per-batch flags beside a running maximum cost the
+// same while every workgroup kept them, and still 1 us per storing kernel when one workgroup in 64 did (six memory-side round
+// trips at the end of a 10 us kernel).  So "clamped" is judged per batch exactly (the batch that first pushes the maximum past
+// 65504 fails its verdict and the record is reset), and "too small" on everything stored since the last reset: a checkpoint
+// whose scale does not fit shows in the first batch; activations that collapse by 2^-20 between two batches of one network on
+// bounded inputs do not occur (ReLU layers are homogeneous in the input, the strip is u8), and the host path - one record per
+// call - still sees them.  This is round 3's guard between two davo_synchronize calls, without its reset at each of them.
+constexpr int RANGE_WORDS = 8, RANGE_SNAP = 6, RANGE_SEQ = 7;
+// the verdict on one layer's maximum, shared by the host (forward.hip: check_range) and the kernel that keeps the inputs when it will fail
+__host__ __device__ inline bool range_value_fails(float vmax) {
+    return !(vmax < 65504.f) || (vmax > 0.f && vmax < 0x1p-11f);      // clamped / inf, or too small for the fp16 pairs' low halves
 }
-// What the last kernel of a ticketed device-path batch needs to copy the inputs into the context's ring slot (api.hip).
-// record: the batch's 8-word range record ([0..5] cnv1..cnv6, [7] = 1 once the copy was taken); null = no copy wanted.
+// a storing epilogue's note in the record: vmax = the wave's largest stored magnitude, leader = one lane of the wave
+// (compiler builtins only, so that this header still needs no HIP header)
+__device__ inline void range_note(unsigned* __restrict__ rec_layer, float vmax, bool leader) {
+    if (!leader) return;
+    const unsigned u = __builtin_bit_cast(unsigned, vmax);
+    if (u > __atomic_load_n(rec_layer, __ATOMIC_RELAXED)) (void)__hip_atomic_fetch_max(rec_layer, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// What the last kernel of a ticketed device-path batch does for the range guard (api.hip, prologue.h): mirror the batch's finished
+// record into page-locked host memory (the host's verdict then costs no copy), and keep the batch's inputs in the context's
+// ring slot if the record fails.  record null = nothing to do; s_img null = no copy wanted ("stable_inputs", "auto_range" 0).
 struct SnapArgs {
-    unsigned* record;
+    unsigned* record;                       // the batch's range record (RANGE_WORDS words, layout above)
+    unsigned* host_mirror;                  // device-visible address of its page-locked host copy
+    unsigned seq;                           // this batch's sequence number (host_mirror[RANGE_SEQ] = seq tells the host the record is final)
     const uint8_t *img, *flow, *seg;        // the caller's buffers (16-byte aligned)
     uint8_t *s_img, *s_flow, *s_seg;        // the ring slot's
     unsigned img_vec, flow_vec_half, flow_vec, seg_vec;      // per window, in 16-byte units: strip, flow planes 0-1, whole flow block, seg

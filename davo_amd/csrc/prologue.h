@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void se_excite(const float* __restrict__ partia
                                                 float* __restrict__ tab, unsigned* __restrict__ range_reset) {
     // a ticketed device-path batch starts its own f16x3 range record (api.hip): first kernel of the forward, so in stream
     // order before any storing epilogue; a null pointer = the record is the caller's business
-    if (range_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) range_reset[threadIdx.x] = 0u;
+    if (range_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) range_reset[RANGE_SNAP] = 0u;   // the per-batch word (params.h)
     se_excite_wave<false>(partial, HW, v, blockIdx.x, blockIdx.y, threadIdx.x, w1, b1, w2, b2, wstatic, tab);
 }
 
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void se_squeeze_excite(const float* __restrict
                                                          const float* __restrict__ wstatic, float* __restrict__ tab,
                                                          unsigned* __restrict__ range_reset) {
     const int chunk = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
-    if (range_reset && chunk == 0 && s == 0 && b == 0 && threadIdx.x < 8) range_reset[threadIdx.x] = 0u;      // as se_excite
+    if (range_reset && chunk == 0 && s == 0 && b == 0 && threadIdx.x == 0) range_reset[RANGE_SNAP] = 0u;      // as se_excite
     const float4* f = reinterpret_cast<const float4*>(flow + ((size_t)b * 4 + s) * HW * 2);
     const int nvec = HW / 2;                                   // HW is a multiple of 16
     const int per = (nvec + SQ_CHUNKS - 1) / SQ_CHUNKS;
@@ -338,12 +338,37 @@ __global__ __launch_bounds__(64) void pose_finish(const float* __restrict__ part
 // anything the caller orders behind the batch (e.g. the H2D of the next batch into the same buffers).  A batch in range -
 // every batch of a well-ranged checkpoint - costs six loads per thread and no copy.  Only flow planes 0 and 1 are read by the
 // path (davo.py:978-982): the first half of every window's block.
-__device__ __forceinline__ void snapshot_inputs_if_range_fails(const SnapArgs& a, unsigned worker, unsigned nworkers) {
-    if (!a.record) return;
-    bool fails = false;
+// phase 1 (top of the kernel, so that the memory-side round trips pass behind the kernel's own work): the maxima, and the first half of the mirror
+struct RangePeek { unsigned w[6]; bool fails; };
+__device__ __forceinline__ RangePeek range_peek(const SnapArgs& a, unsigned worker) {
+    RangePeek r{};
+    if (!a.record) return r;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) fails |= range_value_fails(__uint_as_float(__atomic_load_n(a.record + i, __ATOMIC_RELAXED)));
-    if (!fails) return;
+    for (int i = 0; i < 6; ++i) {
+        r.w[i] = __atomic_load_n(a.record + i, __ATOMIC_RELAXED);
+        r.fails |= range_value_fails(__uint_as_float(r.w[i]));
+    }
+    if (worker == 0) {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store((v4u){r.w[0], r.w[1], r.w[2], r.w[3]}, reinterpret_cast<v4u*>(a.host_mirror));
+    }
+    return r;
+}
+// phase 2 (end of the kernel)
+__device__ __forceinline__ void snapshot_inputs_if_range_fails(const SnapArgs& a, const RangePeek& r, unsigned worker, unsigned nworkers) {
+    if (!a.record) return;
+    const bool copy = r.fails && a.s_img != nullptr;
+    if (worker == 0) {
+        // The host's verdict reads this mirror: no device-to-host copy, no event, no stream to wait for (a synchronous read per
+        // batch made batch 1 host-bound, 0.124 -> 0.36 ms per window; an event per batch costs a marker on the GPU's queue).  Two
+        // 16-byte stores to coherent host memory; the second carries the sequence number and is issued after the first has been
+        // acknowledged, so a host that sees this batch's number sees this batch's maxima.
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_nontemporal_store((v4u){r.w[4], r.w[5], copy ? 1u : 0u, a.seq}, reinterpret_cast<v4u*>(a.host_mirror) + 1);
+        if (copy) a.record[RANGE_SNAP] = 1u;
+    }
+    if (!copy) return;
     const uint4* si = reinterpret_cast<const uint4*>(a.img);
     const uint4* sf = reinterpret_cast<const uint4*>(a.flow);
     const uint4* ss = reinterpret_cast<const uint4*>(a.seg);
@@ -357,7 +382,6 @@ __device__ __forceinline__ void snapshot_inputs_if_range_fails(const SnapArgs& a
         const size_t b = i / a.flow_vec_half, o = i - b * a.flow_vec_half;
         df[b * a.flow_vec + o] = sf[b * a.flow_vec + o];
     }
-    if (worker == 0) a.record[7] = 1u;                    // the host's verdict will find the copy it needs (checked there)
 }
 
 __global__ __launch_bounds__(64) void pose_from_tiles(const float* __restrict__ partial, int NB, int P, int bm,
@@ -365,14 +389,16 @@ __global__ __launch_bounds__(64) void pose_from_tiles(const float* __restrict__ 
                                                       float* __restrict__ pose /*[2B][6]*/, SnapArgs snap) {
     const int i = blockIdx.x;                              // (n, head, k)
     const int n = i / 6, hk = i - n * 6;
+    const RangePeek peek = range_peek(snap, blockIdx.x * 64 + threadIdx.x);
     const float tot = pose_tile_sum<false>(partial, n, hk, P, bm, mtiles, ntiles_n, threadIdx.x);
     if (threadIdx.x == 0) pose[i] = 0.01f * (tot / (float)P + bpred[hk]);
-    snapshot_inputs_if_range_fails(snap, blockIdx.x * 64 + threadIdx.x, gridDim.x * 64);
+    snapshot_inputs_if_range_fails(snap, peek, blockIdx.x * 64 + threadIdx.x, gridDim.x * 64);
 }
 
 // the same guard as a launch of its own, behind the pose heads that are not pose_from_tiles ("fuse_pose" 0, "fold_tails" 1, tiny maps)
 __global__ __launch_bounds__(256) void range_guard_snapshot(SnapArgs snap) {
-    snapshot_inputs_if_range_fails(snap, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+    const RangePeek peek = range_peek(snap, blockIdx.x * 256 + threadIdx.x);
+    snapshot_inputs_if_range_fails(snap, peek, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // Split-K fix-up (forward.hip: small batches): out[m][n] = stored(relu(part[m][0][n] + part[m][1][n] + ...)) in the f16x3
@@ -405,7 +431,7 @@ __global__ __launch_bounds__(256) void splitk_fixup(const float* __restrict__ pa
     if (range) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-        if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > __atomic_load_n(range, __ATOMIC_RELAXED)) atomicMax(range, __float_as_uint(vmax));
+        range_note(range, vmax, (threadIdx.x & 63) == 0);
     }
 }
 

@@ -80,7 +80,7 @@ int davo_forward(davo_ctx* ctx, int B, const uint8_t* img, const float* flow, co
  * With davo_set_inflight(ctx, n > 1) the timed form still waits for its own batch only and the
  * batches of all slots are judged together at davo_synchronize().
  * f16x3 range guard: the asynchronous form cannot know its own result, so every batch gets a range record of its own
- * and is judged later: when its slot of a ring of 4 is needed again (four batches on), at davo_synchronize(), or before
+ * and is judged later: when its slot of a ring of 8 is needed again (eight batches on), at davo_synchronize(), or before
  * anything that changes the storage scales.  A failed verdict RE-ISSUES that batch (see "auto_range" below) and
  * rewrites its pose buffer, so:
  *   - the OUTPUT buffer of a batch must stay alive until davo_synchronize() has returned, and its poses are final only
@@ -88,7 +88,7 @@ int davo_forward(davo_ctx* ctx, int B, const uint8_t* img, const float* flow, co
  *   - the INPUT buffers (16-byte aligned) may be overwritten or recycled as soon as work ordered behind the call on
  *     the context's stream may run (e.g. the next H2D on that stream, or anything behind an event recorded there):
  *     the batch's last kernel sees the finished range record and, if the batch will have to be re-issued, copies
- *     the inputs it was issued on into buffers of the context (1.97 MB per 128x416 window, four batches deep,
+ *     the inputs it was issued on into buffers of the context (1.97 MB per 128x416 window, eight batches deep,
  *     allocated at the first such call); the re-issue reads that copy.  A batch in range - every batch of a
  *     well-ranged checkpoint - copies nothing.  A caller that keeps its inputs unchanged until davo_synchronize()
  *     anyway can save the buffers with davo_set_option(ctx, "stable_inputs", 1); re-issues then read the caller's.
