@@ -215,7 +215,7 @@ def main():
     timing = {"warmup_steps": args.warmup, "settle_steps": settle, "timed_steps": args.steps, "bracketed_every": stride,
               "dominant_launch_ms": head_tail(dom_dur),
               "step_ms_on_stream": head_tail([p / stride for p in dom_period if p >= 0]),
-              "note": "untimed = warmup + settle (clock ramp after idle, DESIGN.md 6a); the timed region is exactly `steps` full "
+              "note": "untimed = warmup + settle (clock ramp after idle, HISTORY.md round 2); the timed region is exactly `steps` full "
                       "forwards; step_ms_on_stream = time between the starts of consecutive bracketed cnv6 launches / stride"}
     plan6 = eng.last_plan(5)                          # [(128-row M tiles, N tile | f16x3 tile id), ...]
     # untimed extra pass, one batch in flight: per-kernel breakdown (every launch bracketed)

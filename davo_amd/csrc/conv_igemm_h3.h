@@ -712,7 +712,7 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
             q[3] += s1 * w0; q[4] += s1 * w1; q[5] += s1 * w2;
 #else
             // Reproducer builds only (tools/build_variant.py _e6 -DDAVO_POSE_EXP=6; tools/exp/flake_count.py, flake_lanes.py;
-            // DESIGN.md section 3; profiles/r04_flake*_variants.log).  The six products as the packed sequence hipcc's SLP
+            // DESIGN.md section 4; profiles/r04_flake*_variants.log).  The six products as the packed sequence hipcc's SLP
             // vectoriser formed here.  6: (q4, q5) by v_pk_fma_f32 ... op_sel:[0,1,0] - the LOW result lane takes the HIGH register
             // of the 64-bit src1 pair: with three or more waves per SIMD and neighbours keeping the matrix pipe busy the selected
             // operand sporadically reads as 0 in lanes 48-63 (the product vanishes, the lane returns its addend): 299 of 299
@@ -892,7 +892,7 @@ void conv_igemm_h3(ConvParamsH p) {
 
 // Main launch (256x256 tiles, shared-tap staging) and remainder launch (128x128 tiles, three ring slots) of one layer as ONE
 // grid.  Workgroups of a launch finish together, so every CU stores its tile at the same moment and nothing computes
-// meanwhile (a few per cent of cnv5 / cnv6); started half a round apart, the two halves of the chip would hide
+// meanwhile (HISTORY.md round 2: a few per cent of cnv5 / cnv6); started half a round apart, the two halves of the chip would hide
 // each other's burst, but a late start idles.  The remainder supplies the offset for free: it is a quarter round of short
 // tiles, so half of the CUs take theirs FIRST and the other half LAST - every CU still runs three long tiles and one
 // short one, the halves' bursts no longer coincide, and the boundary between the two launches is gone.

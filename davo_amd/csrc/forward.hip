@@ -109,7 +109,7 @@ int check_range(davo_ctx* c, const unsigned* raw, const int* shifts) {
 
 namespace {
 
-constexpr int MAX_WEIGHT_CHANNEL_SPREAD_LOG2 = 14;     // f16x3 per-channel guard (weights.hip, DESIGN.md section 3)
+constexpr int MAX_WEIGHT_CHANNEL_SPREAD_LOG2 = 14;     // f16x3 per-channel guard (weights.hip, DESIGN.md section 4)
 constexpr int FOLD_EXCITE_MAX_BATCH = 2;       // auto modes: largest batch that folds the excitation / fuses mask + pack into cnv1
 constexpr int FUSE_PACK_MAX_BATCH = 0;        // measured level at every batch (cnv1 +5 us for mask_pack's 6.7): nowhere by default
 

@@ -331,7 +331,7 @@ int build_packed_weights_h3(davo_ctx* c) {
         int rc = upload_bytes(c, wp.data(), wp.size() * sizeof(_Float16), reinterpret_cast<void**>(&c->d_w3patch));
         if (rc) return rc;
     }
-    {   // Per-channel guard of the f16x3 arithmetic (DESIGN.md section 3).  One power-of-two scale per layer keeps the LAYER's largest
+    {   // Per-channel guard of the f16x3 arithmetic (DESIGN.md section 4).  One power-of-two scale per layer keeps the LAYER's largest
         // activation at [512, 1024); a channel whose activations are 2^-r of that keeps its hi half but loses its lo half below
         // r ~ 12 (absolute error 2^-25 of the stored value), which only matters if the consuming layer multiplies that
         // channel by weights 2^r larger than the others' - visible here, in the weights: the spread of the per-input-channel

@@ -228,7 +228,7 @@ const char* davo_range_report(const davo_ctx* ctx);
  *       (csrc/conv_igemm_h3.h, RATE > 0); 0 = a staged chunk per tap.  Bit-identical results.
  *   "cu_partition" (default 0; with davo_set_inflight(ctx, n > 1)): slot i's stream is CU-masked to its own 1/n of every
  *       XCD's compute units (hipExtStreamCreateWithCUMask) and its launches are planned for that many CUs.  Measured
- *       without gain; kept for experiments.  Results do not change.
+ *       without gain (HISTORY.md round 2); kept for experiments.  Results do not change.
  *   "force_tile" (test hook, default -1 = the launch planner decides): tile id of csrc/plan.h (0 128x32, 1 256x64,
  *       2 256x128, 3 128x256, 4 128x128, 5 256x256, 6 208x256); every f16x3 layer the tile fits is issued as one
  *       launch of that shape.  Poses do not depend on it beyond float32 rounding of the fused pose head's sums.

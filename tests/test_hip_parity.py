@@ -1045,7 +1045,7 @@ def test_per_channel_dynamic_range(c_oracle, H, W, B):
     """Wide dynamic range INSIDE a layer: every other output channel of cnv3 and of cnv5 carries 2^-10 of its
     neighbours' magnitude (the next layer's matching input-channel weights x 2^10: the same network).  One power-of-two
     scale per layer cannot lift those channels, so their hi/lo pairs sit 10 bits lower in the fp16 range; the bar must
-    hold with and without calibration (DESIGN.md section 3: the bound)."""
+    hold with and without calibration (DESIGN.md section 4: the bound)."""
     cfg = parse_version(FLAGSHIP_VERSION)
     img, flow, seg = synth.make_inputs(B, H, W)
     weights = synth.make_weights(cfg)
@@ -1229,7 +1229,7 @@ def test_deep_ring_is_bit_identical(c_oracle, B, H, W):
 def test_pose_is_identical_launch_after_launch(B, tile, c_oracle):
     """Regression: with 128x32 tiles on cnv7 (what the planner picks at batch 1) and three or more workgroups per CU
     (batch >= 3), the fused pose head's sums over tiles that straddle two images came out wrong in one forward in three, by up
-    to 7e-3.  Cause (round 4, DESIGN.md section 3): compiler-formed `v_pk_fma_f32 ... op_sel:[0,1,0]` - the low result lane takes
+    to 7e-3.  Cause (round 4, DESIGN.md section 4): compiler-formed `v_pk_fma_f32 ... op_sel:[0,1,0]` - the low result lane takes
     the high register of src1 - sporadically reads the selected operand as 0 in lanes 48-63 under that occupancy; the library
     holds no packed float32 instruction (tools/check_isa.py).  Two hundred forwards of one batch must agree to the bit, and the
     first of them with the oracle (every forward of the flaking builds could be wrong, the first included)."""

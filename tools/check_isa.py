@@ -21,7 +21,7 @@ from davo_amd._lib import HIPCC_FLAGS                                # noqa: E40
 
 PACKED_F32 = re.compile(r"^\s*(v_pk_(fma|mul|add)_f32)\b")
 # v_pk_*_f32 whose LOW result lane takes the HIGH register of the 64-bit src1 pair (op_sel:[x,1,x]): the one instruction form
-# behind round 3's flaky pose sums (DESIGN.md section 3; profiles/r04_flake*_variants.log)
+# behind round 3's flaky pose sums (DESIGN.md section 4; profiles/r04_flake*_variants.log)
 SRC1_SELECT = re.compile(r"^\s*v_pk_(fma|mul|add)_f32\b.*\bop_sel:\[\s*[01]\s*,\s*1\b")
 
 
@@ -47,7 +47,7 @@ def check_no_packed_f32(path):
         if m:
             hits[kernel] = hits.get(kernel, 0) + 1
         if SRC1_SELECT.match(line):
-            selects.append("%s: `%s': packed float32 with a low-from-high select on src1 (miscomputes on gfx950, DESIGN.md section 3)"
+            selects.append("%s: `%s': packed float32 with a low-from-high select on src1 (miscomputes on gfx950, DESIGN.md section 4)"
                            % (kernel, line.strip()))
     return selects + ["%s: %d packed float32 instruction(s)" % (k, n) for k, n in sorted(hits.items(), key=lambda kv: str(kv[0]))]
 

@@ -1,5 +1,5 @@
 // dispatch_probe.hip — in which order does the hardware hand the workgroups of one launch to the compute units?
-// (experiment behind DESIGN.md 7c "merged main + remainder grid").  One workgroup per CU at a time (140 KB of LDS), a grid of
+// (experiment behind MEASURED_AND_REJECTED.md "merged main + remainder grid").  One workgroup per CU at a time (140 KB of LDS), a grid of
 // n_long "long" and n_short "short" workgroups in the id order of that experiment; every workgroup records where and when it
 // ran.  Build + run:  hipcc --offload-arch=gfx950 -O2 -o /tmp/dispatch_probe tools/exp/dispatch_probe.hip && /tmp/dispatch_probe
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-// pk_fma_probe.hip — does the packed-float32 sequence hipcc formed in the fused pose-head epilogue (DESIGN.md section 3, "A flaky sum")
+// pk_fma_probe.hip — does the packed-float32 sequence hipcc formed in the fused pose-head epilogue (DESIGN.md section 4, "A flaky sum")
 // give launch-to-launch different results on its own?  Every lane runs the exact instruction sequence (fixed registers, inline asm)
 // on its own data, many times, next to the same arithmetic in scalar instructions, and counts disagreements per output.
 //   hipcc --offload-arch=gfx950 -O2 -o pk_fma_probe tools/exp/pk_fma_probe.hip && ./pk_fma_probe [waves per SIMD 1..8] [nops between]
