@@ -1004,6 +1004,36 @@ def test_streaming_caller_recycles_its_input_buffers_before_the_verdict(c_oracle
     e.close()
 
 
+def test_range_tickets_with_two_batches_in_flight(c_oracle):
+    """davo_set_inflight(2): consecutive batches run on two streams and two workspaces, each with a ticket of its own (its
+    record, its copy of the inputs if the verdict fails, its stream to poll).  A checkpoint that trips the guard, ten batches on
+    buffers of their own (with batches in flight on two streams the API gives a caller no point at which a buffer may be
+    recycled short of davo_synchronize): every batch's poses come out oracle-grade, through the ring of eight."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B, n = 2, 10
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, 64, 96, B, _rescaled(weights, 16), "f16x3")
+    data = [synth.make_inputs(B, 64, 96, first_window=2 * k) for k in range(n)]
+    wants = [c_oracle.forward(cfg, *d, weights) for d in data]
+    sets = [tuple(e.alloc(a.nbytes).upload(a) for a in d) + (e.alloc(B * 48),) for d in data]
+    e.set_inflight(2)
+    for k in range(n):
+        e.forward_device(B, *sets[k])
+    e.synchronize()
+    for k in range(n):
+        assert_pose_close(sets[k][3].download((B, 2, 6)), wants[k], "two in flight, batch %d" % k)
+    st = e.range_stats()
+    assert st["reissued"] == 8 and st["recalibrations"] >= 1 and st["f32_batches"] == 0, st      # batches 8, 9 went out on the new scales
+    for k in range(n):                                                  # settled: nothing is re-issued, same poses
+        e.forward_device(B, *sets[k])
+    e.synchronize()
+    assert e.range_stats() == st
+    for k in range(n):
+        assert_pose_close(sets[k][3].download((B, 2, 6)), wants[k], "two in flight, settled, batch %d" % k)
+    e.set_inflight(1)
+    e.close()
+
+
 def test_stable_inputs_reissue_from_the_callers_buffers(c_oracle):
     """"stable_inputs" 1: the caller promises unchanged inputs until the verdict, the library takes no copies and a re-issue
     reads the caller's buffers (the round-3 behaviour, now opt-in)."""
