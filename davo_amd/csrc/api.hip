@@ -736,6 +736,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "share_taps") c->opt_share_taps = value != 0;
     else if (k == "merge_rem") c->opt_merge_rem = value != 0;
     else if (k == "merge_cnv4") c->opt_merge_cnv4 = value != 0;
+    else if (k == "tile_208x128") c->opt_tile_208x128 = value != 0;
     else if (k == "merge_order") c->opt_merge_order = value == 1 ? 1 : 0;
     else if (k == "patch_cnv2") c->opt_patch_cnv2 = value != 0;
     else if (k == "patch_cnv3") c->opt_patch_cnv3 = value != 0;

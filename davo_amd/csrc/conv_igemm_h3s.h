@@ -37,11 +37,18 @@ namespace davo {
 // first touch of every 128-byte pixel slice (0.151 -> 0.140 ms with the input pinned in L2), so its pixel DMA is issued two
 // chunks ahead; the weight DMA of chunk q+1 is issued BEFORE the pixel DMA of chunk q+2, so that "all but the newest
 // four" (vmcnt counts in issue order) is exactly what chunk q+1 needs.
-template <int KS, int STRIDE, int LAYER, int NSA = 2>
-__global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
-    using T = TileS;
-    constexpr int NP = T::NP;
+// WAVES = 4 (round 4): the 208 x 128 tile for cnv4 (128 output channels).  The per-wave code is the 208x256 tile's - a wave owns 32
+// channels for all 208 pixels - with four waves, one per SIMD, one workgroup per CU (116 KB of LDS with three pixel ring slots), and
+// 2B*16 tiles are whole rounds of the 256 CUs where 128-pixel tiles give 3.25.  Bit-identical to the 128x128 kernel
+// (test_tile_208x128_forced_for_cnv4) and MEASURED SLOWER: cnv4 0.100 -> 0.108 ms at B = 32, 0.394 -> 0.408 at B = 128, level at
+// B = 16 (profiles/r04_cnv4_208x128_ab.log) - one wave per SIMD issues its 11 DMA instructions and their address arithmetic into
+// its own matrix stream, with no second wave to cover the chunk boundary.  Offered to the planner only with "tile_208x128" 1.
+template <int KS, int STRIDE, int LAYER, int NSA = 2, int WAVES = 8>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv_igemm_h3s(ConvParamsH p) {
+    using T = TileSW<WAVES>;
+    constexpr int NP = T::NP, NAJ = T::NAJ, RPP = T::RPP;
     static_assert(NSA == 2 || NSA == 3, "pixel ring slots");
+    static_assert(WAVES == 8 || NSA == 3, "the four-wave tile issues weights first, pixels two chunks ahead");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_s[];
     uint8_t* As = smem_s;                              // [NSA][208][128]  pixels
     uint8_t* Bs = smem_s + NSA * T::A_SLOT;            // [2][256][128]  weights
@@ -69,14 +76,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
     const float* __restrict__ bg = p.bias + grp * p.g_bias + ntile * T::BN;
 
     // ---- staging assignment: thread -> rows r0 + 64 j, logical 16-byte unit u of the 128-byte row --------
-    // pixel rows: j = 0..2 for every wave, j = 3 (rows 192..207) for waves 0 and 1 only; weight rows: j = 0..3
+    // pixel rows: j = 0..NAJ-2 for every wave, j = NAJ-1 (rows 192..207) for waves 0 and 1 only; weight rows: j = 0..3
     const int r0 = tid >> 3;
     const int u = (tid & 7) ^ ((r0 >> 1) & 7);
-    const uint8_t* abase[4];
-    int iy0[4], ix0[4];
+    const uint8_t* abase[NAJ];
+    int iy0[NAJ], ix0[NAJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = r0 + 64 * j;
+    for (int j = 0; j < NAJ; ++j) {
+        const int row = r0 + RPP * j;
         const int m = mtile * T::BM + row;
         int pix0 = 0;
         if (row < T::BM && m < p.M) {
@@ -100,11 +107,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
     unsigned boff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int R = r0 + 64 * j;
+        const int R = r0 + RPP * j;
         const int chan = (R & ~31) + 8 * ((R & 15) >> 2) + 4 * ((R >> 4) & 1) + (R & 3);
         boff[j] = (unsigned)(chan * (int)p.w_row_bytes + u * 16);
     }
-    // LDS destinations of this wave's DMA instructions (wave-uniform): row block 8*wave + 64 j
+    // LDS destinations of this wave's DMA instructions (wave-uniform): row block 8*wave + RPP j
     const int a_row_off = 8 * wave_u * 128;
     uint8_t* const a3_dst_fixed = dummy + wave_u * 1024;             // waves >= 2: the 4th pixel load lands here
 
@@ -118,17 +125,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
         const long delta = ((long)dy * p.Win + dx) * p.x_pix_bytes + (long)dma_cblk * 128;         \
         uint8_t* a_ = As + (abuf_) * T::A_SLOT + a_row_off;                                        \
         uint8_t* b_ = Bs + (bbuf_) * T::B_SLOT + a_row_off;                                        \
-        uint8_t* a3_ = wave_u < 2 ? a_ + 192 * 128 : a3_dst_fixed;                                 \
+        uint8_t* a3_ = wave_u < 2 ? a_ + 192 * 128 : a3_dst_fixed;     /* the last pixel pass */       \
         const uint8_t* wq = wg + (long)((qb_) < p.nchunks ? (qb_) : p.nchunks - 1) * 128;
 #define HS_DMA_A(j_)                                                                               \
     {                                                                                              \
         const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
         const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;          \
         __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? abase[j_] + delta : p.zeros),              \
-                                         (lptr_t*)((j_) == 3 ? a3_ : a_ + (j_) * 64 * 128), 16, 0, 0); \
+                                         (lptr_t*)((j_) == NAJ - 1 ? a3_ : a_ + (j_) * RPP * 128), 16, 0, 0); \
     }
 #define HS_DMA_B(j_)                                                                               \
-    __builtin_amdgcn_global_load_lds((gptr_t*)(wq + boff[j_]), (lptr_t*)(b_ + (j_) * 64 * 128), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t*)(wq + boff[j_]), (lptr_t*)(b_ + (j_) * RPP * 128), 16, 0, 0);
     // NSA == 3: the four weight loads first, so the counted wait at the end of the chunk can leave the pixel loads in flight
 #define HS_DMA_SLOT(s_)                                                                            \
     {                                                                                              \
@@ -150,7 +157,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
             if constexpr ((s_) == 5) HS_DMA_A(1)                                                   \
             if constexpr ((s_) == 6) HS_DMA_A(2)                                                   \
             if constexpr ((s_) == 7) HS_DMA_A(3)                                                   \
+            if constexpr ((s_) == 8 && NAJ > 4) HS_DMA_A(NAJ > 4 ? 4 : 0)                          \
+            if constexpr ((s_) == 9 && NAJ > 5) HS_DMA_A(NAJ > 5 ? 5 : 0)                          \
+            if constexpr ((s_) == 10 && NAJ > 6) HS_DMA_A(NAJ > 6 ? 6 : 0)                         \
         }                                                                                          \
+    }
+    // all pixel loads of a chunk (the prologue's)
+#define HS_DMA_A_ALL                                                                               \
+    {                                                                                              \
+        HS_DMA_A(0) HS_DMA_A(1) HS_DMA_A(2) HS_DMA_A(3)                                            \
+        if constexpr (NAJ > 4) { HS_DMA_A(NAJ > 4 ? 4 : 0) HS_DMA_A(NAJ > 5 ? 5 : 0) HS_DMA_A(NAJ > 6 ? 6 : 0) } \
     }
 #define HS_DMA_ADVANCE if (++dma_tq == p.cpb) { dma_tq = 0; ++dma_cblk; }
 
@@ -202,11 +218,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
             HS_MFMA(wh1, XH_, 1, 0) HS_MFMA(wl1, XH_, 1, 0) HS_MFMA(wh1, XL_, 1, 0)                \
         } else {                                                                                   \
             HS_WAIT1(ahead + 1, XH_);                                                              \
-            if constexpr ((I_) >= 1 && (I_) <= 8) HS_DMA_SLOT((I_) - 1)   /* this group's share of the next chunk's DMA */ \
+            if constexpr ((I_) >= 1 && (I_) <= 4 + NAJ) HS_DMA_SLOT((I_) - 1)   /* this group's share of the next chunk's DMA */ \
             HS_MFMA(wh0, XH_, 0, I_) HS_MFMA(wh1, XH_, 1, I_) HS_MFMA(wl0, XH_, 0, I_) HS_MFMA(wl1, XH_, 1, I_) \
             HS_WAIT1(ahead, XL_);                                                                  \
             HS_MFMA(wh0, XL_, 0, I_) HS_MFMA(wh1, XL_, 1, I_)                                      \
-            if constexpr ((I_) >= 1 && (I_) <= 8) {                                                \
+            if constexpr ((I_) >= 1 && (I_) <= 4 + NAJ) {                                          \
                 _Pragma("unroll") for (int r_ = 0; r_ < 6; ++r_) {                                 \
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
                     __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                             \
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
     }
 
     constexpr int WAIT_ALL = (7 << 4) | (15 << 8);                   // vmcnt(0) only
-    constexpr int WAIT_KEEP_A = 4 | (7 << 4) | (15 << 8);            // vmcnt(4): this iteration's four pixel loads stay in flight
+    constexpr int WAIT_KEEP_A = NAJ | (7 << 4) | (15 << 8);          // vmcnt(NAJ): this iteration's pixel loads stay in flight
     {
         // LDS rings: 2 weight slots, NSA pixel slots.  Chunks 0 (.. NSA-2) are fetched up front; in iteration q the weights
         // of chunk q+1 and the pixels of chunk q+NSA-1 are issued from inside the matrix groups of chunk q (address
@@ -253,14 +269,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
             constexpr bool dma_on = true;
             {
                 HS_DMA_SETUP(0, 0, 0)
-                HS_DMA_A(0) HS_DMA_A(1) HS_DMA_A(2) HS_DMA_A(3) HS_DMA_B(0) HS_DMA_B(1) HS_DMA_B(2) HS_DMA_B(3)
+                HS_DMA_A_ALL HS_DMA_B(0) HS_DMA_B(1) HS_DMA_B(2) HS_DMA_B(3)
                 HS_DMA_ADVANCE
             }
             if constexpr (NSA == 3) {
                 if (p.nchunks > 1) {
                     HS_DMA_SETUP(0, 1, 0)
                     (void)b_; (void)wq;
-                    HS_DMA_A(0) HS_DMA_A(1) HS_DMA_A(2) HS_DMA_A(3)
+                    HS_DMA_A_ALL
                 }
                 HS_DMA_ADVANCE
             }
@@ -434,6 +450,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3s(ConvParamsH p) {
 #undef HS_DMA_A
 #undef HS_DMA_B
 #undef HS_DMA_SLOT
+#undef HS_DMA_A_ALL
 #undef HS_DMA_ADVANCE
 #undef HS_RD
 #undef HS_WAIT1

@@ -105,6 +105,7 @@ struct davo_ctx {
     int opt_fold_tails = -1;                   // 0 off | 1 both tails | 2 the excitation only | -1 auto: the excitation at small batches (pose_tail.h: what it costs)               // the excitation MLP and the pose head's tile sum run in the last workgroup of the squeeze / cnv7 launch
     bool opt_deep_ring = true;                 // f16x3: launches of at most one workgroup per CU (batch 1..4) run on LDS rings of 3..6 slots
     int opt_merge_order = 0;                   // merged grids: 0 = short tiles offset inside every XCD, 1 = per XCD (conv_igemm_h3_mainrem)
+    bool opt_tile_208x128 = false;             // f16x3: cnv4 may run on the four-wave 208x128 tile (conv_igemm_h3s.h; measured 8 % behind the 128x128 tile at B = 32: off)
     bool opt_merge_cnv4 = false;               // f16x3: cnv4 as whole rounds of 256x128 tiles + 128x128 remainder tiles in one grid where the batch allows
     bool opt_share_taps = true;                // f16x3: cnv3..cnv6 stage one pixel patch per filter row for its three taps
     bool opt_f32_n16 = true;                   // f32 mode: cnv1 (16 output channels) on the 128x16 tile / v_mfma_f32_16x16x4_f32 instead of the padded 128x32 one

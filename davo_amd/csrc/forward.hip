@@ -176,7 +176,8 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         p.g_w = (long)L.npad_h * p.w_row_bytes; p.g_bias = L.npad_h;
     }
     if (const char* e = tuning_env("DAVO_DBG")) p.dbg = atoi(e);       // tuning build only
-    const bool allow_208 = li >= 4 && L.npad_h == 256;                 // cnv5, cnv6, cnv7: conv_igemm_h3s.h is instantiated for them
+    // cnv5, cnv6, cnv7 (256 channels per group) and cnv4 (128): conv_igemm_h3s.h is instantiated for them
+    const bool allow_208 = (li >= 4 && L.npad_h == 256) || (li == 3 && L.npad_h == 128 && c->opt_tile_208x128);
     std::vector<LaunchH> plan = plan_layer_h3(p.M, L.npad_h, L.groups, L.tile_h, allow_208, c->ncu);
     if (fuse_pose) {      // one launch, one tile shape no taller than an image, so a tile touches <= 2 images
         const int P = Ho * Wo;
@@ -244,7 +245,7 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
     // layer's outputs (not their value: ~1e-7 relative), so batch sizes that split and batch sizes that do not agree to
     // rounding, not to the bit ("split_k" 0 restores the single chain).  (With S parts: S groups, S partial sums.)
     if (c->opt_split_k && !fuse_pose && (li == 4 || li == 5) && L.groups == 1 && plan.size() == 1 && p.y_mode == 1 && L.cout % 32 == 0 &&
-        plan[0].tile != TILE_208x256) {
+        !is_208(plan[0].tile)) {
         const TileShape ts = tile_shape(plan[0].tile);
         const int mtiles = (p.M + ts.bm - 1) / ts.bm, ntn = L.npad_h / ts.bn;
         const long tiles = (long)mtiles * ntn;

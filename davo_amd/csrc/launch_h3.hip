@@ -6,7 +6,7 @@ namespace davo {
 
 hipError_t launch_layer_h3(int layer, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s) {
     using namespace h3impl;
-    if (tile == TILE_208x256) return launch_layer_h3s(layer, p, grid, s);
+    if (is_208(tile)) return launch_layer_h3s(layer, p, grid, s);
     switch (layer) {
         case 0: return launch_tile<7, 2, 1, true, 32>(tile, p, grid, s);
         case 1: return launch_tile<5, 2, 2, true, 32>(tile, p, grid, s);

@@ -131,15 +131,22 @@ template <int WM, int WN, int TM, int TN, int NSTG, int RATE> struct TileX {
 };
 
 // ---- conv_igemm_h3s.h (f16x3, 208-pixel x 256-channel tile) ------------------------------
-struct TileS {
-    static constexpr int BM = 208, BN = 256, THREADS = 512, WAVES = 8;
+// W waves of 32 output channels each: 8 = the 208x256 tile (cnv5, cnv6, cnv7), 4 = the 208x128 tile (cnv4, 128 output channels:
+// four waves, one per SIMD, one workgroup per CU)
+template <int W> struct TileSW {
+    static constexpr int BM = 208, BN = 32 * W, THREADS = 64 * W, WAVES = W;
     static constexpr int NP = BM / 16;                 // 13 pixel groups
     static constexpr int NC = 2;                       // 16-channel groups per wave
+    static constexpr int RPP = THREADS / 8;            // LDS rows one DMA pass of the workgroup covers (8 per wave)
+    static constexpr int NAJ = (BM + RPP - 1) / RPP;   // pixel-row loads per thread and chunk (4 | 7): the last pass holds rows 192..207, waves 0 and 1 only
+    static constexpr int NBJ = BN / RPP;               // weight-row loads per thread and chunk (4)
     static constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128;
-    static constexpr int DUMMY = WAVES * 1024;         // where the waves without a 4th pixel-row load park theirs
+    static constexpr int DUMMY = WAVES * 1024;         // where the waves without a last pixel-row load park theirs
     static constexpr int LDS_BYTES = 2 * (A_SLOT + B_SLOT) + DUMMY;
     static constexpr int lds_bytes(int nsa) { return nsa * A_SLOT + 2 * B_SLOT + DUMMY; }   // nsa pixel ring slots (conv_igemm_h3s NSA)
+    static_assert(NBJ == 4 && 192 + 8 * 2 == BM, "staging shape");
 };
+typedef TileSW<8> TileS;
 
 // ---- conv_patch_h3.h (cnv1 from an LDS patch) ---------------------------------------------
 namespace cp1 {

@@ -66,6 +66,7 @@ TileShape tile_shape(int t) {
         case TILE_128x256: return {128, 256, 512, TileH<2, 4, 2, 2>::LDS_BYTES_DMA};
         case TILE_256x256: return {256, 256, 512, TileH<4, 2, 2, 4>::LDS_BYTES_DMA};
         case TILE_208x256: return {TileS::BM, TileS::BN, TileS::THREADS, TileS::LDS_BYTES};
+        case TILE_208x128: return {TileSW<4>::BM, TileSW<4>::BN, TileSW<4>::THREADS, TileSW<4>::lds_bytes(3)};
         default: return {128, 128, 512, TileH<4, 2, 1, 2>::LDS_BYTES_DMA};
     }
 }
@@ -81,7 +82,8 @@ TileShape tile_shape(int t) {
 // Round 2: 256x256 and 256x128 stage one pixel patch per filter row for its three taps on cnv3..cnv6 (-3 % and -6 %:
 // gpurun_out/ab_r02v.log, ab_r02w.log), which moves 256x128 past 128x128 where no round is left half empty (cnv4 at B=128).
 static TileInfo kTiles[] = {{TILE_256x256, 1, 1.00}, {TILE_128x256, 1, 0.82}, {TILE_256x128, 1, 0.89},
-                            {TILE_128x128, 2, 0.87}, {TILE_256x64, 2, 0.62}, {TILE_128x32, 4, 0.40}, {TILE_208x256, 1, 0.93}};
+                            {TILE_128x128, 2, 0.87}, {TILE_256x64, 2, 0.62}, {TILE_128x32, 4, 0.40}, {TILE_208x256, 1, 0.93},
+                            {TILE_208x128, 1, 0.75}};      // 208x128: cnv4 only, offered with "tile_208x128" 1; fitted on cnv4 at B = 32 (profiles/r04_cnv4_208x128_ab.log)
 
 // tuning build only: DAVO_H3_EFF="e0,e1,e2,e3,e4,e5[,p4]" (and DAVO_H3_EFF208=e) overrides the efficiencies (table order) and 256x64's per_cu
 static void tiles_from_env() {
@@ -121,9 +123,9 @@ std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile,
     };
     auto fits = [&](const TileInfo& t) {
         const int bn = tile_shape(t.id).bn;
-        return bn <= npad && npad % bn == 0 && (t.id != TILE_208x256 || allow_208);
+        return bn <= npad && npad % bn == 0 && (!is_208(t.id) || (allow_208 && bn == npad));
     };
-    if (forced_tile >= 0 && (forced_tile != TILE_208x256 || allow_208)) return {{0, M, forced_tile}};
+    if (forced_tile >= 0 && forced_tile != TILE_MERGED_MARK && (!is_208(forced_tile) || (allow_208 && tile_shape(forced_tile).bn == npad))) return {{0, M, forced_tile}};
     std::vector<LaunchH> best;
     double best_cost = 1e30;
     const char* rf = tuning_env("DAVO_H3_REM_TILE");
@@ -132,7 +134,7 @@ std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile,
         if (!fits(t1)) continue;
         const double c1 = h3_cost(t1, ntiles(t1, M), ncu);
         if (c1 < best_cost - 1e-9) { best_cost = c1; best = {{0, M, t1.id}}; }
-        if (t1.id == TILE_208x256) continue;                               // single launch only
+        if (is_208(t1.id)) continue;                                       // single launch only
         const TileShape s1 = tile_shape(t1.id);
         const long per_round = (long)ncu * t1.per_cu, per_m = (long)(npad / s1.bn) * groups;
         if (per_round % per_m) continue;
@@ -143,7 +145,7 @@ std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile,
         if (rows1 <= 0 || rows1 >= M) continue;
         const double cm = h3_cost(t1, ntiles(t1, rows1), ncu);
         for (const TileInfo& t2 : kTiles) {
-            if (!fits(t2) || t2.id == TILE_208x256) continue;
+            if (!fits(t2) || is_208(t2.id)) continue;
             if (rem_force >= 0 && t2.id != rem_force) continue;
             const double c = cm + h3_cost(t2, ntiles(t2, M - rows1), ncu) + 0.08;      // a second launch: its fill/drain and the kernel boundary
             if (c < best_cost - 1e-9) { best_cost = c; best = {{0, rows1, t1.id}, {rows1, M - rows1, t2.id}}; }
@@ -159,7 +161,7 @@ int plan_single_tile_h3(int M, int npad, int groups, int max_bm, int forced_tile
         double bc = 1e30;
         for (const TileInfo& t : kTiles) {
             const TileShape ts = tile_shape(t.id);
-            if (ts.bn > npad || npad % ts.bn || ts.bm > max_bm || (t.id == TILE_208x256 && !allow_208)) continue;
+            if (ts.bn > npad || npad % ts.bn || ts.bm > max_bm || (is_208(t.id) && !(allow_208 && ts.bn == npad))) continue;
             if (pass == 0 && forced_tile >= 0 && t.id != forced_tile) continue;
             const double cst = h3_cost(t, (long)((M + ts.bm - 1) / ts.bm) * (npad / ts.bn) * groups, ncu);
             if (cst < bc) { bc = cst; best = t.id; }

@@ -210,6 +210,9 @@ const char* davo_range_report(const davo_ctx* ctx);
  *       to the bit).
  *   "f32_n16" (default 1; float32 mode): cnv1 (16 output channels) on a 128x16 tile with v_mfma_f32_16x16x4_f32 instead of the
  *       128x32 tile whose matrix instructions were half padding.  Another order of the same float32 fma chain per output.
+ *   "tile_208x128" (default 0): 1 = cnv4 may run on a 208-pixel x 128-channel tile of four waves (csrc/conv_igemm_h3s.h): whole
+ *       rounds of the 256 CUs at every batch that is a multiple of 8, bit-identical results, measured 8 % slower than the
+ *       128x128 tile at B = 32 and level at B = 16; kept for experiments.
  *   "merge_order" (default 0): where the merged grid takes its offset: 0 = inside every XCD (half of each XCD's CUs run their
  *       short tile first), 1 = per XCD (even XCDs first, odd XCDs last: an XCD's CUs stay in step, a fifth fewer L2 misses,
  *       0.5 % slower).  Bit-identical results.

@@ -770,6 +770,36 @@ def test_tile_208x256_forced(c_oracle, B, H, W):
     e.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 128, 416), (3, 64, 96), (1, 36, 100)])
+def test_tile_208x128_forced_for_cnv4(c_oracle, B, H, W):
+    """cnv4 on the four-wave 208x128 tile (round 4: conv_igemm_h3s with WAVES = 4, one wave per SIMD, three pixel ring slots):
+    whole image rows at 128x416, tiles that straddle images and a ragged last tile at the small shapes.  Same products in the
+    same order per accumulator as the 128x128 kernel: cnv4's activations bit for bit, poses against the oracle."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(B, H, W, first_window=5)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    e = _engine(cfg, H, W, B, weights, "f16x3")
+    e.set_option("split_k", 0)
+    h2, w2 = -(-H // 4), -(-W // 4)
+    e.set_option("tile_208x128", 1)                          # off by default: measured 8 % behind the 128x128 tile at B = 32
+    e.set_option("force_tile", 4)
+    base = e.forward(img, flow, seg).copy()
+    l4 = e.debug_read("cnv4", (2 * B, h2, w2, 128)).copy()
+    e.set_option("force_tile", 8)                            # fits cnv4 only (128 output channels); the other layers keep their plan
+    got = e.forward(img, flow, seg)
+    assert [p[1] for p in e.last_plan(3)] == [8], e.last_plan(3)
+    assert np.array_equal(e.debug_read("cnv4", (2 * B, h2, w2, 128)), l4)
+    assert_pose_close(got, want, "cnv4 on the 208x128 tile")
+    e.set_option("force_tile", -1)
+    e.set_option("tile_208x128", 0)
+    off = e.forward(img, flow, seg)
+    assert [p[1] for p in e.last_plan(3)] != [8]
+    assert_pose_close(off, want, "tile_208x128 = 0")
+    e.close()
+
+
 # ---- main + remainder launch of cnv5 / cnv6 as one grid (conv_igemm_h3_mainrem) ----------------------------
 @pytest.mark.gpu
 def test_merged_main_and_remainder_launch_is_bit_identical(c_oracle):
