@@ -997,17 +997,18 @@ def test_auto_range_device_path_reissues_at_synchronize(c_oracle):
     e.close()
 
 
-def test_streaming_caller_recycles_its_input_buffers_before_the_verdict(c_oracle):
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 128, 416)])
+def test_streaming_caller_recycles_its_input_buffers_before_the_verdict(c_oracle, B, H, W):
     """A double-buffered H2D loop (the shape of a streaming caller): ONE set of input buffers, overwritten with the next
     batch's data - stream-ordered, behind the forward that read them - long before davo_synchronize.  With a checkpoint that
     trips the range guard every batch is re-issued at its verdict: from the context's own copy of what was issued, so every
     batch's poses are oracle-grade although the caller's buffers hold later data by then (round 3 re-issued from the caller's
     pointers: VERDICT r3 item 4).  Eleven batches: more than the ring of eight, so slots are judged and reused while issuing."""
     cfg = parse_version(FLAGSHIP_VERSION)
-    B, n = 2, 11
+    n = 11                     # 64x96: the pose head is two launches and the guard's copy a launch of its own; 128x416: both ride in pose_from_tiles
     weights = synth.make_weights(cfg)
-    e = _engine(cfg, 64, 96, B, _rescaled(weights, 16), "f16x3")
-    data = [synth.make_inputs(B, 64, 96, first_window=3 * k) for k in range(n)]
+    e = _engine(cfg, H, W, B, _rescaled(weights, 16), "f16x3")
+    data = [synth.make_inputs(B, H, W, first_window=3 * k) for k in range(n)]
     wants = [c_oracle.forward(cfg, *d, weights) for d in data]
     d_img, d_flow, d_seg = e.alloc(data[0][0].nbytes), e.alloc(data[0][1].nbytes), e.alloc(data[0][2].nbytes)
     poses = [e.alloc(B * 48) for _ in range(n)]
