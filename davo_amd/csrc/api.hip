@@ -577,7 +577,7 @@ void davo_destroy(davo_ctx* c) {
     for (int r = 0; r < RANGE_RING; ++r) {
         for (void* q : {c->snap_img[r], c->snap_flow[r], c->snap_seg[r]}) if (q) (void)hipFree(q);
     }
-    void* misc[] = {c->d_range_base, c->d_splitk, c->d_pose_tiles, c->d_w1patch, c->d_w2patch, c->d_w3patch, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
+    void* misc[] = {c->d_range_base, c->d_splitk, c->d_pose_tiles, c->d_w1patch, c->d_w2patch, c->d_w3patch, c->d_w1patch_f32, c->d_w2patch_f32, c->d_w3patch_f32, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
     for (auto& pe : c->prof_entries)
         for (auto& ab : pe.pending) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
@@ -744,6 +744,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "deep_ring") c->opt_deep_ring = value != 0;
     else if (k == "split_k") c->opt_split_k = value != 0;
     else if (k == "f32_n16") c->opt_f32_n16 = value != 0;
+    else if (k == "patch_f32") c->opt_patch_f32 = value != 0;
     else if (k == "auto_range") { int rc = judge_all(c); if (rc) return rc; c->opt_auto_range = value != 0; }
     else if (k == "stable_inputs") { int rc = judge_all(c); if (rc) return rc; c->opt_stable_inputs = value != 0; }
     else if (k == "force_tile") {

@@ -131,6 +131,8 @@ struct davo_ctx {
     float *d_wpred = nullptr, *d_bpred = nullptr;
     uint8_t* d_w1patch = nullptr;              // cnv1 B fragments for conv_patch_cnv1_h3
     uint8_t* d_w2patch = nullptr;              // cnv2 B fragments for conv_patch_cnv2_h3
+    float *d_w1patch_f32 = nullptr, *d_w2patch_f32 = nullptr, *d_w3patch_f32 = nullptr;      // float32 mode: cnv1 / cnv2 / cnv3 weights in the patch kernels' register order (conv_patch_f32.h)
+    bool opt_patch_f32 = true;                 // float32 mode: cnv1 / cnv2 / cnv3 from an LDS-staged input patch (conv_patch_f32.h) instead of the implicit GEMM
     uint8_t* d_w3patch = nullptr;              // cnv3 B fragments for conv_patch_cnv3_h3
     // geometry
     int H1, W1, H2, W2, H3, W3;

@@ -346,6 +346,60 @@ int run_cnv2_patch(davo_ctx* c, const void* x, void* y, int NB) {
     return DAVO_OK;
 }
 
+// cnv1 of the float32 mode from an LDS-staged input patch (conv_patch_f32.h); x: the packed float32 input [NB][H][W][8], y: [NB][H1][W1][16]
+int run_cnv1_patch_f32(davo_ctx* c, const void* x, void* y, int NB) {
+    const ConvLayer& L = c->L[0];
+    ConvPatchParams p{};
+    int Ho, Wo, pt, pl;
+    same_pad(c->H, 7, 2, 1, &Ho, &pt);
+    same_pad(c->W, 7, 2, 1, &Wo, &pl);
+    p.x = static_cast<const uint8_t*>(x); p.w = reinterpret_cast<const uint8_t*>(c->d_w1patch_f32); p.bias = L.d_b; p.y = static_cast<uint8_t*>(y);
+    p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
+    p.H = c->H; p.W = c->W; p.Ho = Ho; p.Wo = Wo; p.pad_t = pt; p.pad_l = pl;
+    p.tiles_x = (Wo + cp1::TW - 1) / cp1::TW; p.tiles_y = (Ho + cp1::TH - 1) / cp1::TH;
+    p.ntiles = NB * p.tiles_x * p.tiles_y;
+    c->last_plan[0][0] = ((NB * Ho * Wo + 127) / 128) * 1000 + 99; c->last_plan[0][1] = 0;
+    const int nblk = p.ntiles < 3 * c->ncu ? p.ntiles : 3 * c->ncu;   // three workgroups per CU, each walks its tiles
+    ProfScope ps(c, "cnv1");
+    HIP_TRY(c, launch_cnv1_patch_f32(p, nblk, c->stream));
+    return DAVO_OK;
+}
+
+// cnv2 of the float32 mode from an LDS-staged input patch (conv_patch_f32.h); x: float32 NHWC [NB][H1][W1][16], y: [NB][H2][W2][32]
+int run_cnv2_patch_f32(davo_ctx* c, const void* x, void* y, int NB) {
+    const ConvLayer& L = c->L[1];
+    ConvPatchParams p{};
+    int Ho, Wo, pt, pl;
+    same_pad(c->H1, 5, 2, 1, &Ho, &pt);
+    same_pad(c->W1, 5, 2, 1, &Wo, &pl);
+    p.x = static_cast<const uint8_t*>(x); p.w = reinterpret_cast<const uint8_t*>(c->d_w2patch_f32); p.bias = L.d_b; p.y = static_cast<uint8_t*>(y);
+    p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
+    p.H = c->H1; p.W = c->W1; p.Ho = Ho; p.Wo = Wo; p.pad_t = pt; p.pad_l = pl;
+    p.tiles_x = (Wo + cp2::TW - 1) / cp2::TW; p.tiles_y = (Ho + cp2::TH - 1) / cp2::TH;
+    p.ntiles = NB * p.tiles_x * p.tiles_y;
+    c->last_plan[1][0] = ((NB * Ho * Wo + 127) / 128) * 1000 + 98; c->last_plan[1][1] = 0;
+    const int nblk = p.ntiles < 2 * c->ncu ? p.ntiles : 2 * c->ncu;   // two workgroups per CU (three measured 4 % slower), each walks its tiles
+    ProfScope ps(c, "cnv2");
+    HIP_TRY(c, launch_cnv2_patch_f32(p, nblk, c->stream));
+    return DAVO_OK;
+}
+
+// cnv3 of the float32 mode from an LDS-staged input patch (conv_patch_f32.h); x: float32 NHWC [NB][H2][W2][32], y: [NB][H2][W2][64]
+int run_cnv3_patch_f32(davo_ctx* c, const void* x, void* y, int NB) {
+    const ConvLayer& L = c->L[2];
+    ConvPatchParams p{};
+    p.x = static_cast<const uint8_t*>(x); p.w = reinterpret_cast<const uint8_t*>(c->d_w3patch_f32); p.bias = L.d_b; p.y = static_cast<uint8_t*>(y);
+    p.zeros = reinterpret_cast<const uint8_t*>(c->d_zeros);
+    p.H = c->H2; p.W = c->W2; p.Ho = c->H2; p.Wo = c->W2; p.pad_t = cp3::RATE; p.pad_l = cp3::RATE;
+    p.tiles_x = (p.Wo + cp3::TW - 1) / cp3::TW; p.tiles_y = (p.Ho + cp3::TH - 1) / cp3::TH;
+    p.ntiles = NB * p.tiles_x * p.tiles_y;
+    c->last_plan[2][0] = ((NB * p.Ho * p.Wo + 127) / 128) * 1000 + 97; c->last_plan[2][1] = 0;
+    const int nblk = p.ntiles < 3 * c->ncu ? p.ntiles : 3 * c->ncu;
+    ProfScope ps(c, "cnv3");
+    HIP_TRY(c, launch_cnv3_patch_f32(p, nblk, c->stream));
+    return DAVO_OK;
+}
+
 // cnv3 of the f16x3 path from an LDS-staged input patch (conv_patch_h3.h, conv_patch_cnv3_h3)
 int run_cnv3_patch(davo_ctx* c, const void* x, void* y, int NB) {
     const ConvLayer& L = c->L[2];
@@ -479,9 +533,12 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
                                     fold_pose ? static_cast<float*>(d_pose) : nullptr))) return rc;
         c->cnv7_valid = !pose_fused;
     } else if (c->impl == 0) {
-        if ((rc = run_conv_layer(c, 0, c->d_packed, 8, H, W, a[0], 16, NB))) return rc;
-        if ((rc = run_conv_layer(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, NB))) return rc;
-        if ((rc = run_conv_layer(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, NB))) return rc;
+        if (c->opt_patch_f32 && c->d_w1patch_f32 && c->packed_ld == 8) { if ((rc = run_cnv1_patch_f32(c, c->d_packed, a[0], NB))) return rc; }
+        else if ((rc = run_conv_layer(c, 0, c->d_packed, 8, H, W, a[0], 16, NB))) return rc;
+        if (c->opt_patch_f32 && c->d_w2patch_f32) { if ((rc = run_cnv2_patch_f32(c, a[0], a[1], NB))) return rc; }
+        else if ((rc = run_conv_layer(c, 1, a[0], 16, c->H1, c->W1, a[1], 32, NB))) return rc;
+        if (c->opt_patch_f32 && c->d_w3patch_f32) { if ((rc = run_cnv3_patch_f32(c, a[1], a[2], NB))) return rc; }
+        else if ((rc = run_conv_layer(c, 2, a[1], 32, c->H2, c->W2, a[2], 64, NB))) return rc;
         if ((rc = run_conv_layer(c, 3, a[2], 64, c->H2, c->W2, a[3], 128, NB))) return rc;
         if ((rc = run_conv_layer(c, 4, a[3], 128, c->H2, c->W2, a[4], 256, NB))) return rc;
         if ((rc = run_conv_layer(c, 5, a[4], 256, c->H2, c->W2, a[5], 2 * c6, NB))) return rc;

@@ -47,6 +47,10 @@ hipError_t launch_mask_pack(int ld, const uint8_t* d_img, const float* d_flow, c
 hipError_t launch_cnv1_patch(bool fused, const ConvPatchParams& p, int nblk, hipStream_t s);
 hipError_t launch_cnv2_patch(const ConvPatchParams& p, int nblk, hipStream_t s);
 hipError_t launch_cnv3_patch(const ConvPatchParams& p, int nblk, hipStream_t s);
+// float32 mode (conv_patch_f32.h)
+hipError_t launch_cnv1_patch_f32(const ConvPatchParams& p, int nblk, hipStream_t s);
+hipError_t launch_cnv2_patch_f32(const ConvPatchParams& p, int nblk, hipStream_t s);
+hipError_t launch_cnv3_patch_f32(const ConvPatchParams& p, int nblk, hipStream_t s);
 // split-K fix-up: d_part [M][S][N] float32 partial sums -> the layer's stored activation (ReLU, fp16 hi/lo pairs, range monitor)
 hipError_t launch_splitk_fixup(const float* d_part, long M, int N, int S, int relu, uint8_t* d_y, unsigned* d_range, hipStream_t s);
 hipError_t launch_pose_from_tiles(const float* d_tiles, int NB, int P, int bm, int mtiles, int ntiles_n,

@@ -5,6 +5,7 @@
 #include <utility>
 
 #include "conv_patch_h3.h"
+#include "conv_patch_f32.h"
 #include "launch.h"
 #include "prologue.h"
 
@@ -67,6 +68,27 @@ hipError_t launch_cnv2_patch(const ConvPatchParams& p, int nblk, hipStream_t s) 
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_patch_cnv2_h3), cp2::LDS_BYTES);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(conv_patch_cnv2_h3, dim3(nblk), dim3(cp2::THREADS), cp2::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_cnv1_patch_f32(const ConvPatchParams& p, int nblk, hipStream_t s) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_patch_cnv1_f32), cp1::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_patch_cnv1_f32, dim3(nblk), dim3(cp1::THREADS), cp1::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_cnv2_patch_f32(const ConvPatchParams& p, int nblk, hipStream_t s) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_patch_cnv2_f32), cp2::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_patch_cnv2_f32, dim3(nblk), dim3(cp2::THREADS), cp2::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_cnv3_patch_f32(const ConvPatchParams& p, int nblk, hipStream_t s) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(conv_patch_cnv3_f32), cp3::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_patch_cnv3_f32, dim3(nblk), dim3(cp3::THREADS), cp3::LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

@@ -210,6 +210,40 @@ int build_packed_weights(davo_ctx* c) {
         int rc = upload(c, wp, &c->d_wpred); if (rc) return rc;
         rc = upload(c, bp, &c->d_bpred); if (rc) return rc;
     }
+    {   // float32 patch kernels (conv_patch_f32.h): the weights as the MFMA's A operand, in the order the kernels consume them.
+        // cnv2: [25 taps][2 N groups][4 instructions t][64 lanes]; lane (r = l & 15, kq = l >> 4) of instruction t holds
+        // W[tap][input channel 4 kq + t][output channel 16 ng + r]
+        const HostTensor& t2 = W("pose_exp_net/cnv2/weights");           // [5][5][16][32]
+        std::vector<float> w2((size_t)25 * 2 * 4 * 64);
+        for (int tap = 0; tap < 25; ++tap)
+            for (int ng = 0; ng < 2; ++ng)
+                for (int q = 0; q < 4; ++q)
+                    for (int l = 0; l < 64; ++l)
+                        w2[((size_t)(tap * 2 + ng) * 4 + q) * 64 + l] = t2.data[((size_t)tap * 16 + 4 * (l >> 4) + q) * 32 + 16 * ng + (l & 15)];
+        int rc = upload(c, w2, &c->d_w2patch_f32); if (rc) return rc;
+        // cnv3: [9 taps][4 waves][8 instructions 4 j + t][64 lanes]: W[tap][input channel 4 kq + t + 16 j][output channel 16 wave + r]
+        const HostTensor& t3 = W("pose_exp_net/cnv3/weights");           // [3][3][32][64]
+        std::vector<float> w3((size_t)9 * 4 * 8 * 64);
+        for (int tap = 0; tap < 9; ++tap)
+            for (int wv = 0; wv < 4; ++wv)
+                for (int q = 0; q < 8; ++q)
+                    for (int l = 0; l < 64; ++l)
+                        w3[((size_t)(tap * 4 + wv) * 8 + q) * 64 + l] = t3.data[((size_t)tap * 32 + 4 * (l >> 4) + (q & 3) + 16 * (q >> 2)) * 64 + 16 * wv + (l & 15)];
+        rc = upload(c, w3, &c->d_w3patch_f32); if (rc) return rc;
+        // cnv1: [14 steps = ky x h][8 packed channels c][64 lanes]: lane (r' = output channel, kq) holds W[ky][kx = 4 h + kq][chmap1[c]][r'],
+        // zero for the dummy tap kx = 7 and for packed channels the variant does not have
+        const HostTensor& t1 = W("pose_exp_net/cnv1/weights");           // [7][7][2 cpf][16]
+        const int cin_tf = 2 * cpf;
+        std::vector<float> w1((size_t)14 * 8 * 64, 0.f);
+        for (int st = 0; st < 14; ++st)
+            for (int q = 0; q < 8; ++q)
+                for (int l = 0; l < 64; ++l) {
+                    const int ky = st >> 1, kx = 4 * (st & 1) + (l >> 4), ci = chmap1[q];
+                    if (kx >= 7 || ci < 0 || ci >= cin_tf) continue;
+                    w1[((size_t)st * 8 + q) * 64 + l] = t1.data[(((size_t)ky * 7 + kx) * cin_tf + ci) * 16 + (l & 15)];
+                }
+        rc = upload(c, w1, &c->d_w1patch_f32); if (rc) return rc;
+    }
     c->packed_ready = true;
     return DAVO_OK;
 }

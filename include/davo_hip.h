@@ -210,6 +210,9 @@ const char* davo_range_report(const davo_ctx* ctx);
  *       to the bit).
  *   "f32_n16" (default 1; float32 mode): cnv1 (16 output channels) on a 128x16 tile with v_mfma_f32_16x16x4_f32 instead of the
  *       128x32 tile whose matrix instructions were half padding.  Another order of the same float32 fma chain per output.
+ *   "patch_f32" (default 1; float32 mode): cnv1, cnv2 and cnv3 from an LDS-staged input patch on v_mfma_f32_16x16x4_f32
+ *       (csrc/conv_patch_f32.h: the f16x3 patch kernels' recipe in float32) instead of the implicit GEMM: 0.153 / 0.070 / 0.091
+ *       -> 0.108 / 0.049 / 0.069 ms at B = 32.  Another fixed order of the same float32 fma chain per output.
  *   "tile_208x128" (default 0): 1 = cnv4 may run on a 208-pixel x 128-channel tile of four waves (csrc/conv_igemm_h3s.h): whole
  *       rounds of the 256 CUs at every batch that is a multiple of 8, bit-identical results, measured 8 % slower than the
  *       128x128 tile at B = 32 and level at B = 16; kept for experiments.

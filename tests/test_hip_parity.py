@@ -771,6 +771,34 @@ def test_tile_208x256_forced(c_oracle, B, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 128, 416), (3, 64, 96), (2, 36, 100), (1, 256, 832)])
+def test_f32_patch_kernels_match_the_implicit_gemm(c_oracle, B, H, W):
+    """Float32 mode, round 4: cnv1, cnv2 and cnv3 from an LDS-staged input patch on v_mfma_f32_16x16x4_f32 (csrc/conv_patch_f32.h)
+    instead of the implicit GEMM: another fixed order of the same float32 fma chain per output, so the layers agree to float32
+    rounding (not to the bit), at shapes with whole tiles (128x416, 256x832) and with partial tiles in both directions (64x96:
+    cnv1 32x48, cnv2/3 16x24; 36x100: 18x50, 9x25); poses against the oracle; "patch_f32" 0 restores the implicit GEMM."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(B, H, W, first_window=2)
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, H, W, B, weights, "f32")
+    h1, w1, h2, w2 = -(-H // 2), -(-W // 2), -(-H // 4), -(-W // 4)
+    shapes = {"cnv1": (2 * B, h1, w1, 16), "cnv2": (2 * B, h2, w2, 32), "cnv3": (2 * B, h2, w2, 64)}
+    e.set_option("patch_f32", 0)
+    base = e.forward(img, flow, seg).copy()
+    ref = {k: e.debug_read(k, s).copy() for k, s in shapes.items()}
+    assert [p[1] for p in e.last_plan(1)] != [98]
+    e.set_option("patch_f32", 1)
+    got = e.forward(img, flow, seg)
+    assert [p[1] for p in e.last_plan(0)] == [99] and [p[1] for p in e.last_plan(1)] == [98] and [p[1] for p in e.last_plan(2)] == [97]
+    for k, s in shapes.items():
+        assert_layer_close(e.debug_read(k, s), ref[k], "%s: patch kernel vs implicit GEMM (float32)" % k, rtol=2e-6)
+    assert np.abs(got - base).max() <= 2e-6 * np.abs(base).max()
+    if H * W <= 128 * 416:
+        assert_pose_close(got, c_oracle.forward(cfg, img, flow, seg, weights), "float32 patch kernels %dx%d" % (H, W))
+    e.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W", [(2, 128, 416), (3, 64, 96), (1, 36, 100)])
 def test_tile_208x128_forced_for_cnv4(c_oracle, B, H, W):
     """cnv4 on the four-wave 208x128 tile (round 4: conv_igemm_h3s with WAVES = 4, one wave per SIMD, three pixel ring slots):
