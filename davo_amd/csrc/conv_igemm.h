@@ -217,6 +217,51 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
             }
         return;
     }
+    // ---- pose head in the epilogue (cnv7, float32 mode): fixed summation order -> bitwise reproducible; pose_from_tiles adds the tiles
+    if (p.pose_w) {
+        const int row0 = mtile * BM;
+        const int img0 = row0 / p.pose_P;
+        const int split_row = (img0 + 1) * p.pose_P - row0;          // tile rows >= split_row: next image
+        float q[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            const int n = ntile * BN + wn * T::TN * 32 + j * 32 + li;
+            const bool n_ok = n < p.Cout;
+            const float* wp = p.pose_w + ((long)grp * p.Cout + (n_ok ? n : 0)) * 3;
+            const float w0 = n_ok ? wp[0] : 0.f, w1 = n_ok ? wp[1] : 0.f, w2 = n_ok ? wp[2] : 0.f;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * T::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = fmaxf(acc[i][j][r], 0.f);
+                    if (row0 + row >= p.M) v = 0.f;
+                    if (row < split_row) s0 += v; else s1 += v;
+                }
+            q[0] += s0 * w0; q[1] += s0 * w1; q[2] += s0 * w2;
+            q[3] += s1 * w0; q[4] += s1 * w1; q[5] += s1 * w2;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q[k] += __shfl_down(q[k], o, 64);
+        __syncthreads();                                             // every wave is done with the staging buffers
+        float* red = smem;                                           // [4 waves][6]
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[wid * 6 + k] = q[k];
+        __syncthreads();
+        constexpr int UNITS = BN >= 32 ? BN / 32 : 1;                // 32-column units of this tile
+        if (tid < 6 * UNITS) {
+            const int unit = tid / 6, k = tid - unit * 6;
+            float t = 0.f;
+            if (unit == 0)
+                for (int w = 0; w < 4; ++w) t += red[w * 6 + k];
+            p.pose_partial[(((long)grp * p.pose_mt + mtile) * 8 + ntile * UNITS + unit) * 6 + k] = t;
+        }
+        return;
+    }
     // ---- epilogue: bias + ReLU, C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {

@@ -114,7 +114,8 @@ constexpr int FOLD_EXCITE_MAX_BATCH = 2;       // auto modes: largest batch that
 constexpr int FUSE_PACK_MAX_BATCH = 0;        // measured level at every batch (cnv1 +5 us for mask_pack's 6.7): nowhere by default
 
 // ---- one conv layer, FP32-MFMA path ---------------------------------------------------------------
-int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int Win, float* y, int y_ld, int NB) {
+// fuse_pose (cnv7): the pose head runs in the epilogue (conv_igemm.h); *pose_mt receives the layer's M tiles
+int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int Win, float* y, int y_ld, int NB, bool fuse_pose = false, int* pose_mt = nullptr) {
     const ConvLayer& L = c->L[li];
     ConvParams p{};
     int Ho, Wo, pt, pl;
@@ -133,6 +134,18 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
     const int mtiles = (p.M + BM - 1) / BM;
     std::vector<Launch> plan = plan_layer(mtiles, L.npad, L.groups, c->ncu);
     if (li == 0 && L.cout <= 16 && c->opt_f32_n16) plan = {{0, mtiles, 16}};      // cnv1 on the 128x16 tile at every batch size (conv_igemm.h, N16)
+    if (fuse_pose) {
+        const size_t need = (size_t)L.groups * mtiles * 8 * 6;
+        if (need > c->pose_tiles_floats) {
+            if (c->d_pose_tiles) { int rs = sync_all_slots(c); if (rs) return rs; HIP_TRY(c, hipFree(c->d_pose_tiles)); c->d_pose_tiles = nullptr; }
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_pose_tiles), need * sizeof(float) * 4));   // x4: one region per in-flight slot
+            c->pose_tiles_floats = need;
+        }
+        const int slot_idx = (c->next_slot + c->inflight - 1) % c->inflight;
+        p.pose_w = c->d_wpred; p.pose_partial = c->d_pose_tiles + (size_t)slot_idx * c->pose_tiles_floats;
+        p.pose_P = Ho * Wo; p.pose_mt = mtiles;
+        if (pose_mt) *pose_mt = mtiles;
+    }
     c->last_plan[li][0] = c->last_plan[li][1] = 0;
     for (size_t i = 0; i < plan.size(); ++i) {
         p.mtile0 = plan[i].mtile0;
@@ -542,7 +555,12 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         if ((rc = run_conv_layer(c, 3, a[2], 64, c->H2, c->W2, a[3], 128, NB))) return rc;
         if ((rc = run_conv_layer(c, 4, a[3], 128, c->H2, c->W2, a[4], 256, NB))) return rc;
         if ((rc = run_conv_layer(c, 5, a[4], 256, c->H2, c->W2, a[5], 2 * c6, NB))) return rc;
-        if ((rc = run_conv_layer(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, NB))) return rc;
+        // float32 mode, round 4: the pose head in cnv7's epilogue like the f16x3 path's (the 109 MB activation is neither written nor
+        // read back, pose_head_partial + pose_finish become pose_from_tiles); tiles of 128 rows must not span more than two images
+        pose_fused = c->opt_fuse_pose && c->H3 * c->W3 >= 128 && c->L[6].npad == 256;
+        pose_bm = 128; pose_ntn = 8;
+        if ((rc = run_conv_layer(c, 6, a[5], 2 * c6, c->H2, c->W2, a[6], 512, NB, pose_fused, &pose_mt))) return rc;
+        c->cnv7_valid = !pose_fused;
     } else {
         const std::string P = "pose_exp_net/";
         const int c10 = 2 * v.cin_per_frame;

@@ -35,6 +35,13 @@ struct ConvParams {
     // grouped launch (blockIdx.y = group): per-group strides
     int g_x_coff, g_y_coff;
     long g_w, g_bias;
+    // cnv7 with the pose head in the epilogue (round 4; pred 1x1 + spatial mean are linear, nets/posenn.py:240-241): nothing is
+    // stored but the tile's sum_pixels sum_channels relu(x) * Wpred[c][k], split by image, per 32-column unit:
+    // pose_partial[group][mtile][8 units][2 image slots][3]; a tile wider than 32 columns writes its sum into its first unit and
+    // zeros into the others, so the main (128-column) and the remainder (32-column) launch share one layout for pose_from_tiles
+    const float* pose_w;    // [groups][256][3] pred kernels; null = store the activation as before
+    float* pose_partial;
+    int pose_P, pose_mt;    // output pixels per image (>= 128), M tiles of the whole layer
 };
 
 constexpr int BM = 128;

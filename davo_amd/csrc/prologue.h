@@ -181,8 +181,9 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
     const long total = (long)B * 2 * H * W4;
     const long gid_raw = (long)blockIdx.x * 256 + threadIdx.x;
     const bool valid = gid_raw < total;
-    if (LD != 16 && !valid) return;
-    const long gid = valid ? gid_raw : total - 1;             // LD 16: every thread reaches the barrier below
+    constexpr bool STAGED = LD == 16 || LD == 8;               // 32 B per pixel: the stores leave through LDS (below)
+    if (!STAGED && !valid) return;
+    const long gid = valid ? gid_raw : total - 1;             // staged: every thread reaches the barrier below
     const int x4 = (int)(gid % W4);
     long t = gid / W4;
     const int y = (int)(t % H); t /= H;
@@ -227,11 +228,12 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
     }
     constexpr int OUT_FLOATS = LD == 16 ? 8 : LD;          // LD 16 = split-fp16 layout, 8 floats' worth per pixel
     float* o = out + (((size_t)(b * 2 + s) * H + y) * W + x) * OUT_FLOATS;
-    // LD 16: a thread's 4 pixels are 8 x 16 B, 128 B apart from its neighbour's - stored directly, every store
+    // LD 16 / 8: a thread's 4 pixels are 8 x 16 B, 128 B apart from its neighbour's - stored directly, every store
     // instruction would touch 64 separate lines.  The workgroup's 32 KB (contiguous: output offset = gid * 128 B)
     // go through LDS instead and leave as 1 KiB per wave instruction.  Unit t*8 + (k ^ (t&7)): 2-way bank conflicts
-    // on the way in, none on the way out.
-    __shared__ float4 stage[LD == 16 ? 256 * 8 : 1];
+    // on the way in, none on the way out.  (Round 4: the float32 layout too - mask_pack<8> stored directly until then:
+    // 46 us against mask_pack<16>'s 31 for the same bytes.)
+    __shared__ float4 stage[STAGED ? 256 * 8 : 1];
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
         const float mt = v.mask_rgb ? at[px] : 1.f, ms = v.mask_rgb ? as[px] : 1.f;
@@ -259,15 +261,16 @@ __global__ __launch_bounds__(256) void mask_pack(const uint8_t* __restrict__ img
             stage[t8 + ((2 * px) ^ sw)] = *reinterpret_cast<const float4*>(&hl[0]);
             stage[t8 + ((2 * px + 1) ^ sw)] = *reinterpret_cast<const float4*>(&hl[8]);
         } else if (LD == 8) {
-            *reinterpret_cast<float4*>(o + px * 8) = make_float4(r[0], r[1], r[2], r[3]);
-            *reinterpret_cast<float4*>(o + px * 8 + 4) = make_float4(r[4], r[5], r[6], r[7]);
+            const int t8 = threadIdx.x * 8, sw = threadIdx.x & 7;
+            stage[t8 + ((2 * px) ^ sw)] = make_float4(r[0], r[1], r[2], r[3]);
+            stage[t8 + ((2 * px + 1) ^ sw)] = make_float4(r[4], r[5], r[6], r[7]);
         } else {
             float* q = o + px * 10;
             q[0] = r[0]; q[1] = r[1]; q[2] = r[2]; q[3] = 0.f; q[4] = 0.f;
             q[5] = r[3]; q[6] = r[4]; q[7] = r[5]; q[8] = r[6]; q[9] = r[7];
         }
     }
-    if (LD == 16) {
+    if (STAGED) {
         __syncthreads();
         float4* og = reinterpret_cast<float4*>(out) + (size_t)blockIdx.x * (256 * 8);
 #pragma unroll

@@ -795,6 +795,15 @@ def test_f32_patch_kernels_match_the_implicit_gemm(c_oracle, B, H, W):
     assert np.abs(got - base).max() <= 2e-6 * np.abs(base).max()
     if H * W <= 128 * 416:
         assert_pose_close(got, c_oracle.forward(cfg, img, flow, seg, weights), "float32 patch kernels %dx%d" % (H, W))
+    # the pose head in cnv7's epilogue (float32 mode, round 4; where an image has >= 128 output pixels) against the stored
+    # activation + pose_head_partial / pose_finish: the same sums in another order
+    e.set_option("fuse_pose", 0)
+    unfused = e.forward(img, flow, seg).copy()
+    c7 = e.debug_read("cnv7", (2 * B, -(-H // 8), -(-W // 8), 512))
+    assert np.isfinite(c7).all() and np.abs(unfused - got).max() <= 2e-6 * np.abs(got).max()
+    e.set_option("fuse_pose", 1)
+    again = e.forward(img, flow, seg)
+    assert np.array_equal(again, got)                            # run to run identical
     e.close()
 
 
