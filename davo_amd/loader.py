@@ -479,17 +479,42 @@ def kitti_loader(dump_dir, seq, H, W, lo, hi, batch_size, workers=4, prefetch=2,
         on_close=dec.close if dec else None)
 
 
-def write_synthetic_dump(dump_dir, seq, n_frames, H, W, seed=None, quality=95):
+def scene_like_strip(H, W, window, seed=0):
+    """A u8 [H,3W,3] strip with the statistics of a photograph rather than of white noise: four octaves of smooth random
+    fields per frame plus sensor-like noise.  JPEG cost depends on content: uniform noise at quality 95 (the parity inputs of
+    ``synth.make_inputs``) is 188 KB and 1.3-2.0 ms of libjpeg per 128x1248 strip, the worst case; a strip like this one at
+    quality 75 — the default of ``scipy.misc.imsave``, which wrote the reference's dumps (data/preprocess.py:65) — is ~50 KB: tens of KB,
+    the order of a photographic strip of this size (no KITTI frame is available offline to pin it closer)."""
+    from PIL import Image
+    rng = np.random.default_rng(1000003 * seed + window)
+    out = np.empty((H, 3 * W, 3), np.float32)
+    for f in range(3):
+        acc = np.zeros((H, W, 3), np.float32)
+        for gh, gw, amp in ((3, 6, 70.0), (9, 27, 35.0), (33, 105, 16.0), (65, 209, 12.0)):
+            g = Image.fromarray(rng.integers(0, 256, (gh, gw, 3), dtype=np.uint8))
+            acc += amp * (np.asarray(g.resize((W, H), Image.BILINEAR), np.float32) / 127.5 - 1.0)
+        out[:, f * W:(f + 1) * W] = acc
+    out += 128.0 + rng.normal(0.0, 20.0, out.shape)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def write_synthetic_dump(dump_dir, seq, n_frames, H, W, seed=None, quality=None, images="noise"):
     """Write a dump in the reference's on-disk format from the seeded synthetic tensors (no KITTI offline).
-    Returns the number of windows written."""
+    ``images``: "noise" = the parity inputs' uniform-noise strips at quality 95 (worst case for the decoder), "scene" =
+    ``scene_like_strip`` at quality 75 (a real dump's file size and decode cost).  Returns the number of windows written."""
     from PIL import Image
     from . import synth
+    if images not in ("noise", "scene"):
+        raise ValueError("images must be 'noise' or 'scene'")
+    if quality is None:
+        quality = 95 if images == "noise" else 75
     d = os.path.join(dump_dir, "%.2d" % seq)
     os.makedirs(d, exist_ok=True)
     for w in range(n_frames - 2):
         img, flow, seg = synth.make_inputs(1, H, W, seed=synth.SEED if seed is None else seed, first_window=w)
         jpg, flo, sg = window_paths(dump_dir, seq, w + 1)
-        Image.fromarray(img[0]).save(jpg, quality=quality)
+        strip = img[0] if images == "noise" else scene_like_strip(H, W, w, synth.SEED if seed is None else seed)
+        Image.fromarray(strip).save(jpg, quality=quality)
         np.save(flo, flow[0])
         np.save(sg, seg[0])
     return n_frames - 2

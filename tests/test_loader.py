@@ -230,3 +230,22 @@ def test_emulated_shard_does_one_ranks_work(dump, c_oracle):
     lo, hi = S.shard_windows(n_windows, 3, 1)
     assert (lo, hi) == (3, 6) and timing["windows_this_rank"] == 3 and len(traj) == n_windows + 2
     assert np.array_equal(poses[lo:hi], ref[lo:hi]) and not poses[:lo].any() and not poses[hi:].any()
+
+
+def test_scene_like_dump_is_reproducible_and_far_smaller_than_noise(tmp_path):
+    """images="scene": photograph-like strips at the quality the reference's dumps were written with (scipy.misc.imsave's
+    default 75, data/preprocess.py:65) — same layout, same arrays, a fraction of the noise strips' bytes."""
+    a, b, n = str(tmp_path / "a"), str(tmp_path / "b"), str(tmp_path / "n")
+    assert L.write_synthetic_dump(a, 0, 5, 128, 416, images="scene") == 3
+    L.write_synthetic_dump(b, 0, 5, 128, 416, images="scene")
+    L.write_synthetic_dump(n, 0, 5, 128, 416)
+    ia, fa, sa = L.load_window(a, 0, 2, 128, 416)
+    ib, fb, sb = L.load_window(b, 0, 2, 128, 416)
+    i_n, fn, sn = L.load_window(n, 0, 2, 128, 416)
+    assert np.array_equal(ia, ib) and ia.shape == (128, 1248, 3)
+    assert np.array_equal(fa, fn) and np.array_equal(sa, sn)                 # only the strips differ
+    assert not np.array_equal(L.load_window(a, 0, 1, 128, 416)[0], ia)
+    size = lambda d: os.path.getsize(L.window_paths(d, 0, 2)[0])
+    assert 20_000 < size(a) < 80_000 < size(n)
+    with pytest.raises(ValueError, match="images"):
+        L.write_synthetic_dump(a, 1, 5, 128, 416, images="photo")

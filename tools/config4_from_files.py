@@ -3,7 +3,7 @@
 reference's on-disk format -> CLI (worker-process loader, RCCL all-gather forced at world size 1) -> trajectory, with the run's
 time split.  The dump holds 640 distinct windows; the rest are links to them (same files, same decode work, warm page cache).
 
-    python tools/config4_from_files.py [out.json] [--shard r/R]      # --shard 3/8: only what rank 3 of 8 would do (568 windows)"""
+    python tools/config4_from_files.py [out.json] [--shard r/R] [--images noise|scene]      # --shard 3/8: only what rank 3 of 8 would do (568 windows)"""
 import json
 import os
 import sys
@@ -25,9 +25,13 @@ def main():
     procs = argv.pop(argv.index("--procs") + 1) if "--procs" in argv else None
     if procs:
         argv.remove("--procs")
+    images = argv.pop(argv.index("--images") + 1) if "--images" in argv else "noise"
+    if "--images" in argv:
+        argv.remove("--images")
     out = argv[0] if argv else None
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
-        L.write_synthetic_dump(d, 0, real, H, W)
+        L.write_synthetic_dump(d, 0, real, H, W, images=images)
+        jpg_bytes = sum(os.path.getsize(L.window_paths(d, 0, w + 1)[0]) for w in range(real - 2)) // (real - 2)
         for w in range(real - 2, N - 2):
             for src, dst in zip(L.window_paths(d, 0, (w % (real - 2)) + 1), L.window_paths(d, 0, w + 1)):
                 os.symlink(src, dst)
@@ -43,7 +47,8 @@ def main():
             runs.append(r)
         assert len(open(os.path.join(d, "00-pred_kitti_pose.txt")).read().splitlines()) == N
     rec = {"what": "BASELINE configs[3] shape on ONE rank from files (seq 00: 4541 frames, 4539 windows, batch 64, forced RCCL gather); "
-                   "8 ranks would each take 568 of these windows" + (": THIS run is the work of rank %s" % shard if shard else ""), "runs": runs}
+                   "8 ranks would each take 568 of these windows" + (": THIS run is the work of rank %s" % shard if shard else ""),
+           "images": images, "mean_jpeg_bytes_per_strip": jpg_bytes, "runs": runs}
     print(json.dumps(rec, indent=1))
     if out:
         json.dump(rec, open(out, "w"), indent=1)
