@@ -25,6 +25,11 @@
 
 #include "params.h"
 
+#ifndef DAVO_F32_ABLATE_A
+#define DAVO_F32_ABLATE_A 0    /* timing experiments only: every pixel load reads the zero line / every weight load the first chunk */
+#define DAVO_F32_ABLATE_B 0
+#endif
+
 namespace davo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         const bool ok = tap_ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win; \
         const long off = (long)(pix0[j_] + iy * p.Win + ix) * p.x_ld + c;                          \
         /* unconditional load; a padded tap reads a zero line: no branch around the load */       \
-        dst_ = *reinterpret_cast<const float4*>(ok ? xg + off : p.zeros);                          \
+        dst_ = *reinterpret_cast<const float4*>((ok && !DAVO_F32_ABLATE_A) ? xg + off : p.zeros);  \
     }
 #define DAVO_LOAD_CHUNK(q_)                                                                        \
     {                                                                                              \
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         const int dy = ky * p.rate, dx = kx * p.rate;                                              \
         const bool tap_ok = tap < p.ntaps;                                                         \
         DAVO_LOAD_A(0, ra0) DAVO_LOAD_A(1, ra1) DAVO_LOAD_A(2, ra2) DAVO_LOAD_A(3, ra3)            \
-        const float* wrow = wg + (long)r0 * p.Kpad + kg;                                           \
+        const float* wrow = wg + (long)r0 * p.Kpad + (DAVO_F32_ABLATE_B ? kk : kg);               \
         if (!N16 || r0 < 16) rb0 = *reinterpret_cast<const float4*>(wrow);                         \
         if constexpr (T::NB_LOADS > 1) rb1 = *reinterpret_cast<const float4*>(wrow + 32L * p.Kpad); \
         if constexpr (T::NB_LOADS > 2) {                                                           \
