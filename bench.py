@@ -250,7 +250,10 @@ def main():
             kname = ("davo::%s (cnv6 %s: rotation|translation fused, N=256, K=2304, %s tile, LDS-DMA staged, "
                      "v_mfma_f32_16x16x32_f16)" % ("conv_igemm_h3_mainrem<6,2>" if merged else "conv_igemm_h3<3,1,...,6,true,false,true>",
                                                    "whole layer, one launch" if merged else "main launch", tiles.get(plan[0][1], "?")))
-            peak_note = "fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP; frac = matrix-pipe utilisation"
+            peak_note = ("fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP; frac = matrix-pipe utilisation.  Measured "
+                         "beside it (tools/exp/mfma_peak_probe.hip, profiles/r04d_mfma_peak_probe2.log): under the board power cap a loop of "
+                         "nothing but v_mfma_f32_16x16x32_f16 on random operands sustains 2,029-2,046 TFLOP/s (zeros: 2,437-2,465), and one "
+                         "that also reads its operands from LDS at this tile's 0.25 fragment reads per MFMA 1,602 = 0.64 of the nominal peak")
             key = "conv_igemm_h3_mainrem<6" if merged else "conv_igemm_h3<3, 1, "
         # HBM traffic of the dominant kernel: from the most recent committed PMC pass (profiles/), not live —
         # rocprofv3 counter collection cannot run inside the timed process
