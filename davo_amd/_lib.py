@@ -44,7 +44,7 @@ EXPORTS = (
     "davo_profile_reset", "davo_profile_entry", "davo_profile_samples", "davo_last_plan", "davo_set_option", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
     "davo_host_alloc", "davo_host_free", "davo_host_register", "davo_host_unregister", "davo_calibrate", "davo_activation_range", "davo_set_activation_shifts", "davo_range_stats", "davo_range_report",
     "davo_comm_unique_id", "davo_comm_init", "davo_comm_size", "davo_allgather_poses", "davo_allgather_poses_device",
-    "davo_comm_allreduce", "davo_comm_barrier", "davo_comm_destroy", "davo_plan_layer",
+    "davo_comm_allreduce", "davo_comm_barrier", "davo_comm_destroy", "davo_plan_layer", "davo_tile_filter_rows",
 )
 COMM_ID_BYTES = 128
 
@@ -144,6 +144,7 @@ def lib():
     L.davo_conv2d_same.argtypes = [i, f32p, i, i, i, i, f32p, i, i, f32p, i, i, i, i, f32p, ctypes.c_char_p, i]
     ip = ctypes.POINTER(i)
     L.davo_plan_layer.argtypes = [i, i, i, ip, ip, ip]
+    L.davo_tile_filter_rows.argtypes = [i] * 8 + [ip, ip, i, ip]
     L.davo_comm_unique_id.argtypes = [vp, ctypes.c_char_p, i]
     L.davo_comm_init.argtypes = [vp, i, i, vp]
     L.davo_comm_size.argtypes = [vp, ip, ip]

@@ -579,6 +579,7 @@ void davo_destroy(davo_ctx* c) {
     }
     void* misc[] = {c->d_range_base, c->d_splitk, c->d_pose_tiles, c->d_w1patch, c->d_w2patch, c->d_w3patch, c->d_w1patch_f32, c->d_w2patch_f32, c->d_w3patch_f32, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
+    for (auto& kv : c->tile_orders) if (kv.second) (void)hipFree(kv.second);
     for (auto& pe : c->prof_entries)
         for (auto& ab : pe.pending) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -737,7 +738,8 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "merge_rem") c->opt_merge_rem = value != 0;
     else if (k == "merge_cnv4") c->opt_merge_cnv4 = value != 0;
     else if (k == "tile_208x128") c->opt_tile_208x128 = value != 0;
-    else if (k == "merge_order") c->opt_merge_order = value == 1 ? 1 : 0;
+    else if (k == "merge_order") c->opt_merge_order = value < 0 ? -1 : (value > 2 ? 0 : value);
+    else if (k == "skip_order") c->opt_skip_order = value != 0;
     else if (k == "patch_cnv2") c->opt_patch_cnv2 = value != 0;
     else if (k == "patch_cnv3") c->opt_patch_cnv3 = value != 0;
     else if (k == "fold_tails") c->opt_fold_tails = value < 0 ? -1 : (value > 2 ? 1 : value);
@@ -831,6 +833,17 @@ int davo_debug_read(davo_ctx* c, const char* tensor, float* host_out, size_t n_f
             memcpy(host_out + px * ch, tmp.data(), ch * sizeof(float));
         }
     }
+    return DAVO_OK;
+}
+
+int davo_tile_filter_rows(int m0, int m1, int Hout, int Wout, int Hin, int stride, int pad_t, int rate,
+                          int* ky0, int* nky, int nblocks, int* chunk_map) {
+    if (!ky0 || !nky || Hout < 1 || Wout < 1 || Hin < 1 || stride < 1 || rate < 1 || m0 < 0 || nblocks < 0) return DAVO_ERR_INVALID;
+    const FilterRows fr = valid_filter_rows(m0, m1, Hout, Wout, Hin, stride, pad_t, rate);
+    *ky0 = fr.ky0;
+    *nky = fr.nky;
+    if (chunk_map)
+        for (int v = 0; v < 9 * fr.nky * nblocks / 3; ++v) chunk_map[v] = h3_real_chunk(v, fr.ky0, fr.nky);
     return DAVO_OK;
 }
 

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wid / T::WN, wn = wid % T::WN;
 
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_i = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = p.tile_order ? __builtin_amdgcn_readfirstlane(p.tile_order[tile_i]) : tile_i;
     const int ntile = tile % p.ntiles_n, mtile = p.mtile0 + tile / p.ntiles_n;
     const int grp = blockIdx.y;
     const float* __restrict__ xg = p.x + p.x_coff + grp * p.g_x_coff;
@@ -156,7 +157,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     }
     }
 
-    DAVO_LOAD_CHUNK(0)
+    // chunks of filter rows that only see zero padding for every pixel of this tile are not walked (params.h,
+    // valid_filter_rows): here chunks run tap by tap, so a filter row is one contiguous run of 3 * Cin / 32 chunks.
+    // The skipped terms are exact zeros: the float32 fma chain of every output is the oracle's without them.
+    int q0 = 0, q1 = p.nchunks;
+    if constexpr (KS == 3) {
+        if (p.cin_log2 >= 5) {
+            const FilterRows fr = valid_filter_rows(mtile * BM, min(mtile * BM + BM, p.M) - 1, p.Hout, p.Wout, p.Hin, STRIDE, p.pad_t, p.rate);
+            const int per_row = 3 << (p.cin_log2 - 5);
+            q0 = __builtin_amdgcn_readfirstlane(fr.ky0 * per_row);
+            q1 = __builtin_amdgcn_readfirstlane((fr.ky0 + fr.nky) * per_row);
+        }
+    }
+    DAVO_LOAD_CHUNK(q0)
     DAVO_STORE_CHUNK(0)
     __syncthreads();
 
@@ -198,8 +211,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         }                                                                                          \
     }
 
-    for (int q = 0; q + 1 < p.nchunks; ++q) {
-        const int buf = q & 1;
+    for (int q = q0; q + 1 < q1; ++q) {
+        const int buf = (q - q0) & 1;
         DAVO_LOAD_CHUNK(q + 1)                           // global loads fly under the MFMAs
         __builtin_amdgcn_sched_barrier(0);               // keep hipcc from sinking them to the stores
         DAVO_COMPUTE(buf)
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         DAVO_STORE_CHUNK(buf ^ 1)
         __syncthreads();
     }
-    DAVO_COMPUTE((p.nchunks - 1) & 1)
+    DAVO_COMPUTE((q1 - 1 - q0) & 1)
 
     if constexpr (N16) {       // C/D layout of 16x16x4: col = lane & 15, row = 4 (lane >> 4) + r
         const int n = ntile * BN + l16;

@@ -128,12 +128,30 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
     if (H3_DBG(16384 | 32768) && blockIdx.x < 512 && blockIdx.y == 0 && (H3_DBG(16384) ? ((blockIdx.x >> 3) & 1) : (blockIdx.x & 1)))
         for (int i = 0; i < ((p.dbg >> 16) & 0xff); ++i) __builtin_amdgcn_s_sleep(127);
 #endif
-    const int tile = xcd_remap(wg_x, nwg_x);
+    const int tile_i = xcd_remap(wg_x, nwg_x);
+    const int tile = p.tile_order ? __builtin_amdgcn_readfirstlane(p.tile_order[tile_i]) : tile_i;
     const int ntile = tile % p.ntiles_n, mtile = p.mtile0 + tile / p.ntiles_n;
     const int grp = wg_y;
     const uint8_t* __restrict__ xg = p.x + p.x_boff + grp * p.g_x_boff;
     const uint8_t* __restrict__ wg = p.w + grp * p.g_w + (long)ntile * BNH * p.w_row_bytes;
     const float* __restrict__ bg = p.bias + grp * p.g_bias + ntile * BNH;
+    // Filter rows that reach inside the image for at least one output pixel of this tile: [ky0, ky0 + nky).  The other rows
+    // multiply zero padding only (dilation 8 on a 32-row map: the tiles of image rows 0..7 never see ky = 0, those of rows
+    // 24..31 never ky = 2), so the whole workgroup walks the chunks of the valid rows alone: at 128x416 15 % of cnv5's and
+    // 8 % of cnv4's chunks.  Sums lose terms that are exactly zero; the order of the others is unchanged.
+    int ky0 = 0, nky = KS;
+    if constexpr (KS == 3 && !SMALLC) {
+        const FilterRows fr = valid_filter_rows(mtile * BMH, min(mtile * BMH + BMH, p.M) - 1, p.Hout, p.Wout, p.Hin, STRIDE, p.pad_t, p.rate);
+        ky0 = __builtin_amdgcn_readfirstlane(fr.ky0);
+        nky = __builtin_amdgcn_readfirstlane(fr.nky);
+    }
+    if constexpr (KS == 3 && !SMALLC && !XS) {
+        // the plain ring's prologue puts DMA_STAGES - 1 chunks in flight: a tile left with fewer (split-K parts of one channel
+        // block that keep a single filter row: 3 chunks against a ring of 6) walks all rows as before
+        if ((p.nchunks / p.cpb) * KS * nky < T::DMA_STAGES - 1) { ky0 = 0; nky = KS; }
+    }
+    const int tq0 = (KS == 3 && !SMALLC) ? KS * ky0 : 0, tq1 = (KS == 3 && !SMALLC) ? KS * (ky0 + nky) : p.cpb;   // chunk (tap) range inside a channel block
+    const int nch = (p.nchunks / p.cpb) * (tq1 - tq0);             // chunks this tile walks
 
     // ---- staging assignment: thread -> (row r0 + ROWS_PER_PASS*j, 16-byte unit u of the 128-byte row)
     // unit u: plane = u>>2 (0 = hi, 1 = lo), k-elements 8*(u&3) .. +7 of the chunk
@@ -257,8 +275,9 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
         const long delta = ((long)dy * p.Win + dx) * p.x_pix_bytes + (long)dma_cblk * (cb * 4);    \
         uint8_t* a_ = As + (buf_) * BMH * 128;                                                     \
         uint8_t* b_ = Bs + (buf_) * BNH * 128;                                                     \
-        const uint8_t* wq = wg + (long)((q_) < p.nchunks ? (q_) : p.nchunks - 1) * 128;
-#define H3_DMA_ADVANCE if (++dma_tq == p.cpb) { dma_tq = 0; ++dma_cblk; }
+        const int rq_ = dma_cblk * p.cpb + dma_tq;          /* the chunk's index in the layer's weight rows */ \
+        const uint8_t* wq = wg + (long)(rq_ < p.nchunks ? rq_ : p.nchunks - 1) * 128;
+#define H3_DMA_ADVANCE if (++dma_tq == tq1) { dma_tq = tq0; ++dma_cblk; }
     // slot s of the 8 DMA issue slots of a chunk: 0..3 = A rows, 4..7 = B rows
 #define H3_DMA_SLOT(s_)                                                                            \
     {                                                                                              \
@@ -279,7 +298,7 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
         H3_DMA_B(0) H3_DMA_B(1) H3_DMA_B(2) H3_DMA_B(3)                                            \
         H3_DMA_ADVANCE                                                                             \
     }
-    int dma_cblk = 0, dma_tq = 0;
+    int dma_cblk = 0, dma_tq = tq0;
     // one 32-k chunk = two K=16 MFMA steps; per step and output tile: hi*hi, hi*lo, lo*hi
 #define H3_STEP32(buf_, s_)                                                                        \
     {                                                                                              \
@@ -495,7 +514,7 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
         H3_RD(bl[1], b_l, 16 * ROWB);                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         uint8_t* b_ = Bs + nslot * BNH * 128;                                                      \
-        const uint8_t* wq = wg + (long)(q + NST - 1 < p.nchunks ? q + NST - 1 : p.nchunks - 1) * 128; \
+        const uint8_t* wq = wg + (long)h3_real_chunk(q + NST - 1 < nch ? q + NST - 1 : nch - 1, ky0, nky) * 128; \
         H3_GROUPX(0, KX_, nabuf_) H3_GROUPX(1, KX_, nabuf_) H3_GROUPX(2, KX_, nabuf_) H3_GROUPX(3, KX_, nabuf_)    \
         H3_GROUPX(4, KX_, nabuf_) H3_GROUPX(5, KX_, nabuf_) H3_GROUPX(6, KX_, nabuf_) H3_GROUPX(7, KX_, nabuf_)    \
     }
@@ -568,17 +587,17 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
             // fetches the next weight chunk into the ring as before.  Patch slots past the super-chunks (and weight chunks
             // past the end) are issued all the same, reading the zero line: the per-chunk instruction count stays constant
             // for the counted wait, and no branch cuts the interleaved code.
-            const int nsc = p.nchunks / 3;
-            int xcblk = 0, xky = 0;
+            const int nsc = nch / 3;
+            int xcblk = 0, xky = ky0;
             {
-                const int xdy = 0, xdp_ = 0, xcoff = 0;
+                const int xdy = ky0 * RATE, xdp_ = ky0 * RATE * p.Win, xcoff = 0;
                 H3_XDMA_A(0, 0) H3_XDMA_A(1, 0) H3_XDMA_A(2, 0)
                 if constexpr (XSLOTS > 3) H3_XDMA_A(3, 0)
                 if constexpr (XSLOTS > 4) H3_XDMA_A(4, 0)
                 static_assert(XSLOTS <= 5, "patch slots per thread");
-                for (int c0 = 0; c0 < NST - 1 && c0 < p.nchunks; ++c0) {
+                for (int c0 = 0; c0 < NST - 1 && c0 < nch; ++c0) {
                     uint8_t* b_ = Bs + c0 * BNH * 128;
-                    const uint8_t* wq = wg + (long)c0 * 128;
+                    const uint8_t* wq = wg + (long)h3_real_chunk(c0, ky0, nky) * 128;
                     H3_DMA_B(0) H3_DMA_B(1) H3_DMA_B(2) H3_DMA_B(3)
                 }
             }
@@ -592,7 +611,7 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
             {                                                                                      \
                 const int nslot = slot == 0 ? NST - 1 : slot - 1;                                  \
                 H3_CHUNK16X(KX_, slot, abuf, nabuf)                                                \
-                if (q + 1 < p.nchunks) {                                                           \
+                if (q + 1 < nch) {                                                                 \
                     /* the patch of the next super-chunk must have landed when its first chunk starts: drain after kx = 2 */ \
                     if (NST >= 3 && KX_ != 2) __builtin_amdgcn_s_waitcnt(XWAIT_KEEP);              \
                     else __builtin_amdgcn_s_waitcnt(WAIT_ALL);                                     \
@@ -602,7 +621,7 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
                 ++q;                                                                               \
             }
             for (int sc = 0; sc < nsc; ++sc) {
-                if (++xky == 3) { xky = 0; ++xcblk; }                 // the super-chunk whose patch this one fetches
+                if (++xky == ky0 + nky) { xky = ky0; ++xcblk; }       // the super-chunk whose patch this one fetches
                 const int xdy = sc + 1 < nsc ? xky * RATE : -(1 << 28);
                 const int xdpix = xky * RATE * p.Win, xcoff = xcblk * 128;
                 const int abuf = sc & 1, nabuf = abuf ^ 1;
@@ -614,20 +633,20 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
         H3_DMA_CHUNK(0, 0)
         if constexpr (NST >= 3) {
             static_assert(NST <= 6, "ring depth");
-            if (p.nchunks >= NST - 1) {
+            if (nch >= NST - 1) {
                 H3_DMA_CHUNK(1, 1)
                 if constexpr (NST >= 4) H3_DMA_CHUNK(2, 2)
                 if constexpr (NST >= 5) H3_DMA_CHUNK(3, 3)
                 if constexpr (NST >= 6) H3_DMA_CHUNK(4, 4)
             }
         }
-        if (NST >= 3 && p.nchunks >= NST - 1) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
+        if (NST >= 3 && nch >= NST - 1) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
         else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
         __builtin_amdgcn_s_barrier();
         int slot = 0;                                         // slot of chunk q
-        for (int q = 0; q < p.nchunks; ++q) {
+        for (int q = 0; q < nch; ++q) {
             const int nslot = slot == 0 ? NST - 1 : slot - 1; // (q + NST - 1) % NST
-            const bool more = q + NST - 1 < p.nchunks;
+            const bool more = q + NST - 1 < nch;
             if constexpr (M16) {
                 // the next chunk's DMA is issued from inside the matrix groups (H3_GROUP), two or four instructions
                 // per group over the first half of the chunk: its address arithmetic runs in the shadow of queued
@@ -646,9 +665,9 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
                 if (more && late_dma && !H3_DBG(1)) H3_DMA_CHUNK(q + NST - 1, nslot)
                 if (!H3_DBG(2)) H3_STEP32(slot, 1)
             }
-            if (q + 1 < p.nchunks) {
+            if (q + 1 < nch) {
                 // M16: the filler DMA keeps the count of younger instructions constant, so the counted wait always holds
-                if (NST >= 3 && (more || M16) && p.nchunks >= NST - 1) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
+                if (NST >= 3 && (more || M16) && nch >= NST - 1) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
                 else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
                 __builtin_amdgcn_s_barrier();
             }
@@ -919,6 +938,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_h3_mainrem(ConvParamsH pm, 
         if (x & 1) { rem = i >= nl; ord = ((rem ? i - nl : i) << 3) | x; }
         else { rem = i < ns; ord = ((rem ? i : i - ns) << 3) | x; }
     }
+    else if (order == 2) { rem = b >= n_main; ord = rem ? b - n_main : b; }     // long tiles first (pm.tile_order), the short remainder tiles fill the end
     else if (b < 2 * h) { rem = ((b >> 5) & 1) == 0; ord = ((b >> 6) << 5) | (b & 31); }
     else if (b < h + n_main) { rem = false; ord = b - h; }
     else { rem = true; ord = b - n_main; }

@@ -113,6 +113,49 @@ constexpr int MAX_WEIGHT_CHANNEL_SPREAD_LOG2 = 14;     // f16x3 per-channel guar
 constexpr int FOLD_EXCITE_MAX_BATCH = 2;       // auto modes: largest batch that folds the excitation / fuses mask + pack into cnv1
 constexpr int FUSE_PACK_MAX_BATCH = 0;        // measured level at every batch (cnv1 +5 us for mask_pack's 6.7): nowhere by default
 
+// ---- long tiles first ------------------------------------------------------------------------------
+// The 3x3 kernels skip the chunks of filter rows that are all padding for a tile (params.h, valid_filter_rows), so the tiles
+// of one launch differ in length (dilation 8 on a 32-row map: 6 of an image's 13 tiles of 256 pixels walk two thirds of the
+// chunks).  Workgroups are handed out strictly in id order, an XCD's to its four shader engines round-robin
+// (tools/exp/dispatch_probe.hip), and a launch is three to six rounds of tiles: in natural order some CUs draw long tiles
+// every round and the launch is as long as before.  The table puts, inside every XCD's contiguous run of tiles (xcd_remap),
+// the long tiles first (stable, so neighbours stay neighbours): every engine then sees the same long-first sequence and
+// the short tiles pack the end.  Returns nullptr when all tiles of the launch cost the same.
+const int* tile_order_for(davo_ctx* c, int li, int kind, int bm, int mtile0, int mtiles, int ntiles_n, int M,
+                          int Hout, int Wout, int Hin, int stride, int pad_t, int rate) {
+    if (!c->opt_skip_order) return nullptr;
+    const std::vector<int> key = {li, kind, bm, mtile0, mtiles, ntiles_n, M, Hout, Wout};
+    auto it = c->tile_orders.find(key);
+    if (it != c->tile_orders.end()) return it->second;
+    const int nt = mtiles * ntiles_n;
+    std::vector<int> cost(nt), order(nt);
+    bool uniform = true;
+    for (int t = 0; t < nt; ++t) {
+        const int m0 = (mtile0 + t / ntiles_n) * bm, m1 = std::min(m0 + bm, M) - 1;
+        cost[t] = valid_filter_rows(m0, m1, Hout, Wout, Hin, stride, pad_t, rate).nky;
+        uniform = uniform && cost[t] == cost[0];
+    }
+    int* dev = nullptr;
+    if (!uniform) {
+        const int q = nt >> 3, r = nt & 7;
+        for (int x = 0; x < 8; ++x) {                       // xcd_remap: XCD x runs tiles [start, start + len)
+            const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, len = q + (x < r ? 1 : 0);
+            int w = start;
+            for (int want = 3; want >= 1; --want)
+                for (int t = start; t < start + len; ++t)
+                    if (cost[t] == want) order[w++] = t;
+        }
+        if (hipMalloc(reinterpret_cast<void**>(&dev), nt * sizeof(int)) != hipSuccess ||
+            hipMemcpy(dev, order.data(), nt * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            if (dev) (void)hipFree(dev);
+            dev = nullptr;                                   // not fatal: natural order
+            (void)hipGetLastError();
+        }
+    }
+    c->tile_orders[key] = dev;
+    return dev;
+}
+
 // ---- one conv layer, FP32-MFMA path ---------------------------------------------------------------
 // fuse_pose (cnv7): the pose head runs in the epilogue (conv_igemm.h); *pose_mt receives the layer's M tiles
 int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int Win, float* y, int y_ld, int NB, bool fuse_pose = false, int* pose_mt = nullptr) {
@@ -151,6 +194,7 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
         p.mtile0 = plan[i].mtile0;
         p.ntiles_n = plan[i].BN == 16 ? 1 : L.npad / plan[i].BN;
         dim3 grid(plan[i].mtiles * p.ntiles_n, L.groups);
+        p.tile_order = (L.KS == 3 && L.cin_log2 >= 5) ? tile_order_for(c, li, 0, BM, plan[i].mtile0, plan[i].mtiles, p.ntiles_n, p.M, Ho, Wo, Hin, L.stride, pt, L.rate) : nullptr;
         const std::string label = i == 0 ? std::string(L.label) : std::string(L.label) + ".rem";
         ProfScope ps(c, label.c_str());
         HIP_TRY(c, launch_layer(li, plan[i].BN, p, grid, c->stream));
@@ -242,9 +286,11 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         // the shape test comes first: a profiling scope is opened only around a launch that is really issued
         // (an empty event pair under the layer's label would halve its average and advance the stride counter twice)
         if (layer_h3_mainrem_supported(li, pm, n_main, n_rem)) {
+            pm.tile_order = tile_order_for(c, li, 1, 256, 0, n_main, 1, pm.M, Ho, Wo, Hin, L.stride, pt, L.rate);
+            const int order = c->opt_merge_order >= 0 ? c->opt_merge_order : (pm.tile_order ? 2 : 0);
             {
                 ProfScope ps(c, L.label);
-                HIP_TRY(c, launch_layer_h3_mainrem(li, pm, n_main, pr, n_rem, c->opt_merge_order, c->stream));
+                HIP_TRY(c, launch_layer_h3_mainrem(li, pm, n_main, pr, n_rem, order, c->stream));
             }
             c->last_plan[li][0] = ((plan[0].rows + plan[1].rows + 127) / 128) * 1000 + 7;     // 7: 256x256 + 128x128 in one grid
             return DAVO_OK;
@@ -300,6 +346,8 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         dim3 grid(mtiles * p.ntiles_n, L.groups);
         p.deep = c->opt_deep_ring && plan.size() == 1 && (long)grid.x * grid.y <= c->ncu;       // at most one workgroup per CU
         c->last_plan[li][i] = ((plan[i].rows + 127) / 128) * 1000 + plan[i].tile;
+        // no tile order here: cnv4's single launch of 128x128 tiles (two per CU, 6.5 rounds) measured 94.4 us in natural order and
+        // 97.4 long-first (profiles/r04e_skip_padding_rows.md); the merged grids above and the float32 launches take one
         const std::string label = i == 0 ? std::string(L.label) : std::string(L.label) + ".rem";
         {
             ProfScope ps(c, label.c_str());

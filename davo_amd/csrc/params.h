@@ -14,6 +14,33 @@ struct Variant {
     int cin_per_frame, cnv6_out, se_act, norm_flow, abs_mode, att_source, mask_rgb, mask_info;
 };
 
+// ---- filter rows that only see padding ------------------------------------------------------
+// 3x3 layers: the filter rows ky that land inside the image for at least one output pixel of the flattened pixel range
+// [m0, m1] are [ky0, ky0 + nky); a range that crosses an image boundary keeps all three.  A tile whose pixels all sit in
+// the top `rate` rows of the map never sees ky = 0 (TF pads with zeros above the image: nets/posenn.py:213-215, dilation 2,
+// 4, 8 on 32-row maps), one in the bottom rows never ky = 2: the convolution kernels skip those rows' chunks per tile.
+struct FilterRows { int ky0, nky; };
+__host__ __device__ inline FilterRows valid_filter_rows(int m0, int m1, int Hout, int Wout, int Hin, int stride, int pad_t, int rate) {
+    FilterRows fr = {0, 3};
+    const int hw = Hout * Wout;
+    const int n0 = m0 / hw;
+    if (m1 < m0 || m1 / hw != n0) return fr;
+    const int ymin = (m0 - n0 * hw) / Wout, ymax = (m1 - n0 * hw) / Wout;
+    int lo = 0, hi = 2;
+    while (lo < hi && ymax * stride - pad_t + lo * rate < 0) ++lo;
+    while (hi > lo && ymin * stride - pad_t + hi * rate > Hin - 1) --hi;
+    fr.ky0 = lo;
+    fr.nky = hi - lo + 1;
+    return fr;
+}
+// f16x3 kernels walk chunks channel block by channel block, nine taps each: the v-th chunk of a tile that keeps filter rows
+// [ky0, ky0 + nky) is chunk (block * 3 + ky) * 3 + kx of the layer's weight rows
+__host__ __device__ inline int h3_real_chunk(int v, int ky0, int nky) {
+    const int sc = v / 3, kx = v - 3 * sc;
+    const int blk = nky == 3 ? sc / 3 : (nky == 2 ? sc >> 1 : sc);
+    return (blk * 3 + ky0 + (sc - blk * nky)) * 3 + kx;
+}
+
 // ---- conv_igemm.h (FP32 MFMA) ------------------------------------------------------------
 struct ConvParams {
     const float* x;       // input activation, pixel-major NHWC
@@ -27,6 +54,7 @@ struct ConvParams {
     int y_ld, y_coff;     // floats per output pixel, first channel written
     int Cout;             // valid output channels (per group)
     int pad_t, pad_l, rate;
+    const int* tile_order;   // or null: tile_order[i] = the tile the i-th workgroup (after xcd_remap) takes (long tiles first, forward.hip)
     int M;                // images * Hout * Wout
     int nchunks, Kpad, ntaps;
     int ntiles_n;
@@ -83,6 +111,7 @@ struct ConvParamsH {
     int y_mode, y_ld, y_coff, Cout;
     int pad_t, pad_l, rate;
     int M, ntaps, ntiles_n, mtile0, relu;
+    const int* tile_order;  // or null: as ConvParams::tile_order
     int Mtot;               // output rows of the whole layer (M is this launch's upper row bound): shared-tap staging reads the
                             // pixels RATE before and after a tile, which may belong to the layer's other launch
     int xs;                 // host: issue the shared-tap instantiation (conv_igemm_h3 RATE > 0) where the layer has one

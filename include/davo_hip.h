@@ -216,9 +216,13 @@ const char* davo_range_report(const davo_ctx* ctx);
  *   "tile_208x128" (default 0): 1 = cnv4 may run on a 208-pixel x 128-channel tile of four waves (csrc/conv_igemm_h3s.h): whole
  *       rounds of the 256 CUs at every batch that is a multiple of 8, bit-identical results, measured 8 % slower than the
  *       128x128 tile at B = 32 and level at B = 16; kept for experiments.
- *   "merge_order" (default 0): where the merged grid takes its offset: 0 = inside every XCD (half of each XCD's CUs run their
- *       short tile first), 1 = per XCD (even XCDs first, odd XCDs last: an XCD's CUs stay in step, a fifth fewer L2 misses,
- *       0.5 % slower).  Bit-identical results.
+ *   "merge_order" (default -1 = 2 where the launch has a tile order, see "skip_order", else 0): how the merged grid interleaves
+ *       its two tile shapes: 0 = offset inside every XCD (half of each XCD's CUs run their short tile first), 1 = per XCD (even
+ *       XCDs first, odd XCDs last: an XCD's CUs stay in step, a fifth fewer L2 misses, 0.5 % slower), 2 = all main tiles, long
+ *       ones first, then the remainder tiles.  Bit-identical results.
+ *   "skip_order" (default 1): the 3x3 kernels do not walk the chunks of a filter row that is zero padding for every pixel of
+ *       a tile (davo_tile_filter_rows), so the tiles of a launch differ in length; 1 = every XCD's run of tiles is handed out
+ *       long tiles first (a device table per launch shape), 0 = natural order.  Bit-identical results.
  *   "merge_cnv4" (default 0): cnv4 as whole rounds of 256x128 tiles + 128x128 remainder tiles in one grid like cnv5 / cnv6
  *       ("merge_rem"); measured level with the single launch of 128x128 tiles.  Bit-identical results.
  *   "fuse_pack" (default -1 = auto, which is off: measured level at every batch): 1 = cnv1 builds its input patch from
@@ -295,6 +299,14 @@ int davo_conv2d_same(int device, const float* x, int N, int H, int W, int Cin,
  * channels (x groups) is issued.  Up to two launches: rows[i] output rows in tiles of tile_bm[i] x
  * tile_bn[i]; returns the number of launches (1 or 2) or a negative davo_status. */
 int davo_plan_layer(int M, int npad, int groups, int* rows, int* tile_bm, int* tile_bn);
+
+/* The per-tile rule of the 3x3 kernels on its own (no GPU needed): a tile that covers the flattened output pixels [m0, m1]
+ * of a [*, Hout, Wout] map walks only the filter rows [*ky0, *ky0 + *nky) that reach inside the Hin-row input for at
+ * least one of its pixels (slim.conv2d pads with zeros: nets/posenn.py:205-215); the chunks of the other rows multiply
+ * padding only and are skipped.  chunk_map[v], v < 3 * 3 * nky * nblocks (optional, may be NULL): index, in the layer's
+ * weight rows, of the v-th chunk the f16x3 kernels walk for such a tile.  Returns DAVO_OK or a negative davo_status. */
+int davo_tile_filter_rows(int m0, int m1, int Hout, int Wout, int Hin, int stride, int pad_t, int rate,
+                          int* ky0, int* nky, int nblocks, int* chunk_map);
 
 #ifdef __cplusplus
 }

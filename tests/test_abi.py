@@ -94,3 +94,40 @@ def test_launch_planner_covers_every_row(built):
             if n == 2:
                 assert rows[0] % bm[0] == 0 and rows[0] % bm[1] == 0
     assert L.davo_plan_layer(0, 256, 1, rows, bm, bn) < 0 and L.davo_plan_layer(100, 48, 1, rows, bm, bn) < 0
+
+
+def test_tile_filter_rows_against_brute_force(built):
+    """davo_tile_filter_rows (host logic, no GPU): the filter rows a tile keeps are exactly those with an in-image tap for
+    some pixel of the tile; every dropped (pixel, ky) pair is zero padding; the chunk map enumerates, in order, the kept
+    taps of every channel block.  Shapes: the PoseNN maps at 128x416 / 256x832 / 64x96 / 32x416 with the tile heights the
+    kernels use, dilation 1..8, stride 1 and 2."""
+    L = ctypes.CDLL(built)
+    ip = ctypes.POINTER(ctypes.c_int)
+    L.davo_tile_filter_rows.argtypes = [ctypes.c_int] * 8 + [ip, ip, ctypes.c_int, ip]
+    skipped = 0
+    for (Hout, Wout, stride, rate, nimg) in ((32, 104, 1, 8, 2), (32, 104, 1, 4, 2), (32, 104, 1, 2, 2), (16, 52, 2, 1, 3), (64, 208, 1, 8, 1),
+                                              (16, 24, 1, 8, 3), (8, 104, 1, 8, 2), (8, 104, 1, 2, 2), (13, 43, 1, 4, 3)):
+        Hin = Hout * stride
+        pad_t = max((Hout - 1) * stride + 2 * rate + 1 - Hin, 0) // 2            # TF SAME (oracle/davo_oracle.py)
+        M = nimg * Hout * Wout
+        for bm in (128, 208, 256):
+            for m0 in range(0, M, bm):
+                m1 = min(m0 + bm, M) - 1
+                ky0, nky = ctypes.c_int(), ctypes.c_int()
+                cmap = (ctypes.c_int * 64)()
+                assert L.davo_tile_filter_rows(m0, m1, Hout, Wout, Hin, stride, pad_t, rate, ky0, nky, 2, cmap) == 0
+                want = set()
+                for m in range(m0, m1 + 1):
+                    y = (m % (Hout * Wout)) // Wout
+                    want |= {ky for ky in range(3) if 0 <= y * stride - pad_t + ky * rate < Hin}
+                kept = set(range(ky0.value, ky0.value + nky.value))
+                assert want <= kept, (Hout, Wout, rate, bm, m0)                   # never drops a row that has a real tap
+                if m0 // (Hout * Wout) == m1 // (Hout * Wout):
+                    assert kept == set(range(min(want), max(want) + 1))            # one image: the tightest contiguous range
+                else:
+                    assert kept == {0, 1, 2}
+                skipped += 3 - nky.value
+                exp = [(blk * 3 + ky) * 3 + kx for blk in range(2) for ky in range(ky0.value, ky0.value + nky.value) for kx in range(3)]
+                assert [cmap[v] for v in range(len(exp))] == exp
+    assert skipped > 0
+    assert L.davo_tile_filter_rows(0, 10, 0, 104, 32, 1, 8, 8, ctypes.c_int(), ctypes.c_int(), 0, None) < 0

@@ -432,6 +432,28 @@ def test_minimum_sizes(c_oracle, H, W, B):
         e.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,B", [(32, 416, 4), (32, 416, 16), (64, 832, 8), (128, 416, 9)])
+def test_tiles_that_skip_padding_rows_of_the_filter(c_oracle, H, W, B):
+    """The 3x3 kernels do not walk the chunks of a filter row that only sees zero padding for every pixel of a tile
+    (davo_tile_filter_rows).  32-row frames have 8-row maps, where dilation 8 leaves the centre row alone (one of three
+    filter rows kept, every tile) and dilation 4 keeps two; 64x832 and 128x416 mix tiles that keep two and three rows, at
+    batch sizes that give single-tile-shape, split-K and main + remainder plans.  Per-layer activations and poses against
+    the oracle, both arithmetic modes; the shared-tap kernels' tiles against the plain ones to the bit."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(B, H, W, first_window=3)
+    weights = synth.make_weights(cfg)
+    want = c_oracle.forward(cfg, img, flow, seg, weights)
+    for precision in PRECISIONS:
+        e = _engine(cfg, H, W, B, weights, precision)
+        got = e.forward(img, flow, seg)
+        assert_pose_close(got, want, "%dx%d B=%d %s" % (H, W, B, precision))
+        if precision == "f16x3":
+            e.set_option("share_taps", 0)
+            assert np.array_equal(e.forward(img, flow, seg), got)
+        e.close()
+
+
 # ---- BASELINE.json configurations at full size ---------------------------------------------------
 def test_config2_batch32_full_size(c_oracle):
     """configs[1]: B=32, 128x416 — every window against the C oracle (multi-launch plan, remainder tiles)."""
