@@ -92,22 +92,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     // written float4 array in scratch and serialises every load behind a scratch store.
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define DAVO_LOAD_A(j_, dst_)                                                                      \
+    // Pixel addresses are carried from chunk to chunk: with Cin >= 32 a tap spans Cin / 32 consecutive chunks whose loads differ
+    // by 32 channels (128 bytes) only, so the ~17 instructions per row of the bounds test and the 64-bit offset (several
+    // quarter-rate integer multiplies) are paid on a tap's first chunk and the others add a step (0 for a row that reads the
+    // zero line).  cnv6 (8 chunks per tap): 68 -> ~20 address instructions per chunk on average.
+    const float *pa0 = p.zeros, *pa1 = p.zeros, *pa2 = p.zeros, *pa3 = p.zeros;
+    int st0 = 0, st1 = 0, st2 = 0, st3 = 0;                       // floats to the same pixel's next 32 channels, or 0
+    const int cpt = p.cin_log2 >= 5 ? 1 << (p.cin_log2 - 5) : 1;  // chunks per tap
+    int l_cb = 0;                                                 // chunk inside the current tap (every launch starts on a tap boundary)
+#define DAVO_ADDR_A(j_, ptr_, st_)                                                                 \
     {                                                                                              \
         const int iy = iy0[j_] + dy, ix = ix0[j_] + dx;                                            \
-        const bool ok = tap_ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win; \
+        const bool ok = tap_ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win && !DAVO_F32_ABLATE_A; \
         const long off = (long)(pix0[j_] + iy * p.Win + ix) * p.x_ld + c;                          \
         /* unconditional load; a padded tap reads a zero line: no branch around the load */       \
-        dst_ = *reinterpret_cast<const float4*>((ok && !DAVO_F32_ABLATE_A) ? xg + off : p.zeros);  \
+        ptr_ = ok ? xg + off : p.zeros;                                                            \
+        st_ = ok ? BK : 0;                                                                         \
     }
 #define DAVO_LOAD_CHUNK(q_)                                                                        \
     {                                                                                              \
         const int kg = (q_) * BK + kk;                                                             \
-        const int tap = kg >> p.cin_log2, c = kg & cmask;                                          \
-        const int ky = tap / KS, kx = tap - ky * KS;                                               \
-        const int dy = ky * p.rate, dx = kx * p.rate;                                              \
-        const bool tap_ok = tap < p.ntaps;                                                         \
-        DAVO_LOAD_A(0, ra0) DAVO_LOAD_A(1, ra1) DAVO_LOAD_A(2, ra2) DAVO_LOAD_A(3, ra3)            \
+        if (l_cb == 0) {                                                                           \
+            const int tap = kg >> p.cin_log2, c = kg & cmask;                                      \
+            const int ky = tap / KS, kx = tap - ky * KS;                                           \
+            const int dy = ky * p.rate, dx = kx * p.rate;                                          \
+            const bool tap_ok = tap < p.ntaps;                                                     \
+            DAVO_ADDR_A(0, pa0, st0) DAVO_ADDR_A(1, pa1, st1) DAVO_ADDR_A(2, pa2, st2) DAVO_ADDR_A(3, pa3, st3) \
+        } else {                                                                                   \
+            pa0 += st0; pa1 += st1; pa2 += st2; pa3 += st3;                                        \
+        }                                                                                          \
+        l_cb = l_cb + 1 == cpt ? 0 : l_cb + 1;                                                     \
+        ra0 = *reinterpret_cast<const float4*>(pa0);                                               \
+        ra1 = *reinterpret_cast<const float4*>(pa1);                                               \
+        ra2 = *reinterpret_cast<const float4*>(pa2);                                               \
+        ra3 = *reinterpret_cast<const float4*>(pa3);                                               \
         const float* wrow = wg + (long)r0 * p.Kpad + (DAVO_F32_ABLATE_B ? kk : kg);               \
         if (!N16 || r0 < 16) rb0 = *reinterpret_cast<const float4*>(wrow);                         \
         if constexpr (T::NB_LOADS > 1) rb1 = *reinterpret_cast<const float4*>(wrow + 32L * p.Kpad); \
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     }
 }
 
-#undef DAVO_LOAD_A
+#undef DAVO_ADDR_A
 #undef DAVO_LOAD_CHUNK
 #undef DAVO_STORE_CHUNK
 #undef DAVO_COMPUTE
