@@ -739,7 +739,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "merge_cnv4") c->opt_merge_cnv4 = value != 0;
     else if (k == "tile_208x128") c->opt_tile_208x128 = value != 0;
     else if (k == "merge_order") c->opt_merge_order = value < 0 ? -1 : (value > 2 ? 0 : value);
-    else if (k == "skip_order") c->opt_skip_order = value != 0;
+    else if (k == "skip_order") c->opt_skip_order = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (k == "patch_cnv2") c->opt_patch_cnv2 = value != 0;
     else if (k == "patch_cnv3") c->opt_patch_cnv3 = value != 0;
     else if (k == "fold_tails") c->opt_fold_tails = value < 0 ? -1 : (value > 2 ? 1 : value);

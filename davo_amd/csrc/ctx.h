@@ -105,7 +105,7 @@ struct davo_ctx {
     int opt_fold_tails = -1;                   // 0 off | 1 both tails | 2 the excitation only | -1 auto: the excitation at small batches (pose_tail.h: what it costs)               // the excitation MLP and the pose head's tile sum run in the last workgroup of the squeeze / cnv7 launch
     bool opt_deep_ring = true;                 // f16x3: launches of at most one workgroup per CU (batch 1..4) run on LDS rings of 3..6 slots
     int opt_merge_order = -1;                  // merged grids: 0 = short tiles offset inside every XCD, 1 = per XCD, 2 = main tiles (long first) then the remainder; -1 = 2 where a tile order exists, else 0
-    bool opt_skip_order = true;                // launches whose tiles skip different numbers of padding rows of the filter hand out the long tiles first (tile_order_for, forward.hip)
+    int opt_skip_order = 1;                    // launches whose tiles skip different numbers of padding rows of the filter hand out the long tiles first (tile_order_for, forward.hip): 0 = never, 1 = float32 launches, 2 = the f16x3 merged grids too
     std::map<std::vector<int>, int*> tile_orders;   // device tables of those launches, by (layer, tile rows, tiles, ...); nullptr = uniform
     bool opt_tile_208x128 = false;             // f16x3: cnv4 may run on the four-wave 208x128 tile (conv_igemm_h3s.h; measured 8 % behind the 128x128 tile at B = 32: off)
     bool opt_merge_cnv4 = false;               // f16x3: cnv4 as whole rounds of 256x128 tiles + 128x128 remainder tiles in one grid where the batch allows

@@ -286,7 +286,9 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         // the shape test comes first: a profiling scope is opened only around a launch that is really issued
         // (an empty event pair under the layer's label would halve its average and advance the stride counter twice)
         if (layer_h3_mainrem_supported(li, pm, n_main, n_rem)) {
-            pm.tile_order = tile_order_for(c, li, 1, 256, 0, n_main, 1, pm.M, Ho, Wo, Hin, L.stride, pt, L.rate);
+            // f16x3: long-first measured 256.8 against 259.9 us on cnv5 with a third more HBM reads (205 -> 272 MB: neighbours no longer
+            // run side by side) and no change of the power-capped step: natural order unless "skip_order" is 2
+            pm.tile_order = c->opt_skip_order >= 2 ? tile_order_for(c, li, 1, 256, 0, n_main, 1, pm.M, Ho, Wo, Hin, L.stride, pt, L.rate) : nullptr;
             const int order = c->opt_merge_order >= 0 ? c->opt_merge_order : (pm.tile_order ? 2 : 0);
             {
                 ProfScope ps(c, L.label);

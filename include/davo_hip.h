@@ -221,8 +221,10 @@ const char* davo_range_report(const davo_ctx* ctx);
  *       XCDs first, odd XCDs last: an XCD's CUs stay in step, a fifth fewer L2 misses, 0.5 % slower), 2 = all main tiles, long
  *       ones first, then the remainder tiles.  Bit-identical results.
  *   "skip_order" (default 1): the 3x3 kernels do not walk the chunks of a filter row that is zero padding for every pixel of
- *       a tile (davo_tile_filter_rows), so the tiles of a launch differ in length; 1 = every XCD's run of tiles is handed out
- *       long tiles first (a device table per launch shape), 0 = natural order.  Bit-identical results.
+ *       a tile (davo_tile_filter_rows), so the tiles of a launch differ in length; every XCD's run of tiles can be handed out
+ *       long tiles first (a device table per launch shape): 0 = never, 1 = in the float32 launches (cnv5 850 -> 793 us),
+ *       2 = in the f16x3 merged grids too (cnv5 259.9 -> 256.8 us, a third more HBM reads, same step time under the power cap).
+ *       Bit-identical results.
  *   "merge_cnv4" (default 0): cnv4 as whole rounds of 256x128 tiles + 128x128 remainder tiles in one grid like cnv5 / cnv6
  *       ("merge_rem"); measured level with the single launch of 128x128 tiles.  Bit-identical results.
  *   "fuse_pack" (default -1 = auto, which is off: measured level at every batch): 1 = cnv1 builds its input patch from

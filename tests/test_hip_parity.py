@@ -454,6 +454,27 @@ def test_tiles_that_skip_padding_rows_of_the_filter(c_oracle, H, W, B):
         e.close()
 
 
+@pytest.mark.gpu
+def test_long_tiles_first_is_bit_identical():
+    """"skip_order": which workgroup takes which tile never changes a tile's arithmetic.  B = 32 at 128x416 (cnv5's merged grid:
+    6 of every 13 main tiles skip a filter row; float32 cnv5 / cnv6 launches): natural order, the default (float32 launches
+    long-first) and everything long-first give the same poses to the bit in both modes."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    B = 32
+    img, flow, seg = synth.make_inputs(8, 128, 416, first_window=40)
+    img, flow, seg = np.tile(img, (4, 1, 1, 1)), np.tile(flow, (4, 1, 1, 1, 1)), np.tile(seg, (4, 1, 1, 1, 1))
+    weights = synth.make_weights(cfg)
+    for precision in PRECISIONS:
+        e = _engine(cfg, 128, 416, B, weights, precision)
+        got = {}
+        for order in (1, 0, 2):
+            e.set_option("skip_order", order)
+            got[order] = e.forward(img, flow, seg)
+        assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2]), precision
+        assert np.array_equal(got[1][:8], got[1][8:16])          # the same windows in other tiles of the batch
+        e.close()
+
+
 # ---- BASELINE.json configurations at full size ---------------------------------------------------
 def test_config2_batch32_full_size(c_oracle):
     """configs[1]: B=32, 128x416 — every window against the C oracle (multi-launch plan, remainder tiles)."""
