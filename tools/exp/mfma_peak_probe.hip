@@ -22,10 +22,18 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 __device__ inline float rnd(unsigned s) { s = s * 747796405u + 2891336453u; s = ((s >> ((s >> 28) + 4)) ^ s) * 277803737u; return ((s >> 9) & 0xffff) * (1.0f / 32768.0f) - 1.0f; }
 
 // every kernel: 16 matrix instructions per iteration, accumulators updated in place (dst = src C), independent chains
+// mode: 0 random, 1 zeros, 2 / 3 / 4: random with the low 4 / 7 / 10 mantissa bits of BOTH operands cleared (how the power of a
+// product depends on the populated bits of its operands)
+__device__ inline _Float16 mask_low(_Float16 x, int mode) {
+    if (mode < 2) return x;
+    unsigned short u = __builtin_bit_cast(unsigned short, x);
+    u &= (unsigned short)(0xffffu << (mode == 2 ? 4 : mode == 3 ? 7 : 10));
+    return __builtin_bit_cast(_Float16, u);
+}
 __global__ __launch_bounds__(256) void k_f16_16(float* out, int iters, int zero) {
     const unsigned t = blockIdx.x * 256 + threadIdx.x;
     half8 a[2], b[2];
-    for (int i = 0; i < 2; ++i) for (int k = 0; k < 8; ++k) { a[i][k] = zero ? (_Float16)0 : (_Float16)rnd(t * 64 + i * 8 + k); b[i][k] = zero ? (_Float16)0 : (_Float16)(rnd(t * 64 + 32 + i * 8 + k) * 0.02f); }
+    for (int i = 0; i < 2; ++i) for (int k = 0; k < 8; ++k) { a[i][k] = zero == 1 ? (_Float16)0 : mask_low((_Float16)rnd(t * 64 + i * 8 + k), zero); b[i][k] = zero == 1 ? (_Float16)0 : mask_low((_Float16)(rnd(t * 64 + 32 + i * 8 + k) * 0.02f), zero); }
     f32x4 acc[8];
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
     for (int it = 0; it < iters; ++it) {
@@ -141,8 +149,9 @@ int main(int argc, char** argv) {
     const double flop_iter[6] = {16.0 * 2 * 16 * 16 * 32, 16.0 * 2 * 32 * 32 * 16, 16.0 * 2 * 32 * 32 * 2, 16.0 * 2 * 16 * 16 * 32, 16.0 * 2 * 16 * 16 * 32, 16.0 * 2 * 16 * 16 * 32};
     const int iters[6] = {20000, 10000, 5000, 20000, 20000, 20000};
     for (int kind = 0; kind < 6; ++kind)
-        for (int zero = 0; zero < 2; ++zero)
-            for (int wps : {1, 2}) {
+        for (int zero = 0; zero < 5; ++zero)
+            for (int wps : {2}) {
+                if (kind >= 1 && zero >= 2) continue;
                 if (kind >= 3 && zero) continue;
                 const int blocks = ncu * wps;
                 const double flops = flop_iter[kind] * iters[kind] * 4.0 * blocks;
@@ -177,7 +186,7 @@ int main(int argc, char** argv) {
                 stop.store(true); sampler.join();
                 size_t best = 0;
                 for (size_t i = 1; i < hw.size(); ++i) if (psum[i] > psum[best]) best = i;
-                printf("%-26s %-7s %5d %10.0f %8.0f %8.0f\n", names[kind], zero ? "zero" : "random", wps, flops * n_late / (ms_late * 1e-3) * 1e-12,
+                printf("%-26s %-7s %5d %10.0f %8.0f %8.0f\n", names[kind], zero == 0 ? "random" : zero == 1 ? "zero" : zero == 2 ? "rnd-4b" : zero == 3 ? "rnd-7b" : "rnd-10b", wps, flops * n_late / (ms_late * 1e-3) * 1e-12,
                        hw.empty() || !nsamp ? -1.0 : psum[best] / nsamp, hw.empty() || !nsamp ? -1.0 : fsum[best] / nsamp);
                 fflush(stdout);
             }
