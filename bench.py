@@ -272,8 +272,17 @@ def main():
                     break
         except (OSError, ValueError, KeyError):
             pass
+        ceiling = None
+        if precision != "f32":
+            # what loops of nothing but v_mfma_f32_16x16x32_f16 sustain on this chip class under the board power cap
+            # (tools/exp/mfma_peak_probe.hip; measured on another box of the pool, committed under profiles/): context for `frac`
+            ceiling = {"unit": "TFLOP/s of fp16 products", "this_kernel_products": round(3.0 * achieved, 1),
+                       "pure_mfma_loop_random_operands": 2040.0, "pure_mfma_loop_zero_operands": 2450.0,
+                       "mfma_loop_fed_from_lds_at_this_tiles_ratio": 1602.0,
+                       "frac_of_lds_fed_loop": round(3.0 * achieved / 1602.0, 4),
+                       "source": "profiles/r04d_mfma_peak_probe.log, profiles/r04d_mfma_peak_probe2.log"}
         return {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "frac": round(achieved / peak, 4), "measured_ceiling": ceiling, "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                 "peak_note": peak_note, "avg_launch_ms": round(avg6, 4), "launches_timed": n6, "flops_per_launch": flops_main,
                 "launch_plan": "cnv6 as %s (mtiles of 128 rows, N tile)" % plan}
