@@ -843,7 +843,7 @@ int davo_tile_filter_rows(int m0, int m1, int Hout, int Wout, int Hin, int strid
     *ky0 = fr.ky0;
     *nky = fr.nky;
     if (chunk_map)
-        for (int v = 0; v < 9 * fr.nky * nblocks / 3; ++v) chunk_map[v] = h3_real_chunk(v, fr.ky0, fr.nky);
+        for (int v = 0; v < 3 * fr.nky * nblocks; ++v) chunk_map[v] = h3_real_chunk(v, fr.ky0, fr.nky);
     return DAVO_OK;
 }
 

@@ -305,7 +305,7 @@ int davo_plan_layer(int M, int npad, int groups, int* rows, int* tile_bm, int* t
 /* The per-tile rule of the 3x3 kernels on its own (no GPU needed): a tile that covers the flattened output pixels [m0, m1]
  * of a [*, Hout, Wout] map walks only the filter rows [*ky0, *ky0 + *nky) that reach inside the Hin-row input for at
  * least one of its pixels (slim.conv2d pads with zeros: nets/posenn.py:205-215); the chunks of the other rows multiply
- * padding only and are skipped.  chunk_map[v], v < 3 * 3 * nky * nblocks (optional, may be NULL): index, in the layer's
+ * padding only and are skipped.  chunk_map[v], v < 3 * nky * nblocks (optional, may be NULL): index, in the layer's
  * weight rows, of the v-th chunk the f16x3 kernels walk for such a tile.  Returns DAVO_OK or a negative davo_status. */
 int davo_tile_filter_rows(int m0, int m1, int Hout, int Wout, int Hin, int stride, int pad_t, int rate,
                           int* ky0, int* nky, int nblocks, int* chunk_map);
