@@ -233,7 +233,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         const int buf = (q - q0) & 1;
         DAVO_LOAD_CHUNK(q + 1)                           // global loads fly under the MFMAs
         __builtin_amdgcn_sched_barrier(0);               // keep hipcc from sinking them to the stores
+        DAVO_PRIO_UP(DAVO_MMPRIO);                       // the wave that has MFMAs to issue wins the arbitration (params.h)
         DAVO_COMPUTE(buf)
+        DAVO_PRIO_DOWN(DAVO_MMPRIO);
         __builtin_amdgcn_sched_barrier(0);
         DAVO_STORE_CHUNK(buf ^ 1)
         __syncthreads();

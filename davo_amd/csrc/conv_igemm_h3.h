@@ -436,7 +436,9 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
         /* the scalar walk to the next chunk (tap, channel block, addresses) runs behind the reads it does not feed */ \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         H3_DMA_SETUP(q + NST - 1, nslot)                                                           \
+        DAVO_PRIO_UP(DAVO_MMPRIO_H3);                                                              \
         H3_GROUP(0) H3_GROUP(1) H3_GROUP(2) H3_GROUP(3) H3_GROUP(4) H3_GROUP(5) H3_GROUP(6) H3_GROUP(7)    \
+        DAVO_PRIO_DOWN(DAVO_MMPRIO_H3);                                                            \
         H3_DMA_ADVANCE                                                                             \
     }
     // ---- XS: the same hand-scheduled chunk with the A fragments read RATE*kx rows down the shared patch -------------
@@ -515,8 +517,10 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
         __builtin_amdgcn_sched_barrier(0);                                                         \
         uint8_t* b_ = Bs + nslot * BNH * 128;                                                      \
         const uint8_t* wq = wg + (long)h3_real_chunk(q + NST - 1 < nch ? q + NST - 1 : nch - 1, ky0, nky) * 128; \
+        DAVO_PRIO_UP(DAVO_MMPRIO_H3);                                                              \
         H3_GROUPX(0, KX_, nabuf_) H3_GROUPX(1, KX_, nabuf_) H3_GROUPX(2, KX_, nabuf_) H3_GROUPX(3, KX_, nabuf_)    \
         H3_GROUPX(4, KX_, nabuf_) H3_GROUPX(5, KX_, nabuf_) H3_GROUPX(6, KX_, nabuf_) H3_GROUPX(7, KX_, nabuf_)    \
+        DAVO_PRIO_DOWN(DAVO_MMPRIO_H3);                                                            \
     }
 #define H3_STEP(buf_, s_)                                                                          \
     {                                                                                              \

@@ -4,6 +4,19 @@
 #pragma once
 #include <stdint.h>
 
+// Matrix phases raise the wave's issue priority (s_setprio): where a SIMD holds waves of several workgroups, the one that
+// has MFMAs to issue then wins the arbitration against the others' address arithmetic, LDS traffic and stores, and the matrix
+// pipe starves less (conv_igemm_f32 cnv6 main launch 1.706 -> 1.672 ms; levels 1, 2, 3 measured alike; the patch kernels of both
+// modes measured level with it and do without).  0 = off.
+#ifndef DAVO_MMPRIO
+#define DAVO_MMPRIO 1
+#endif
+#ifndef DAVO_MMPRIO_H3
+#define DAVO_MMPRIO_H3 0          /* f16x3 kernels: see the measurement in profiles/r04n_setprio.md */
+#endif
+#define DAVO_PRIO_UP(level_) do { if ((level_) > 0) __builtin_amdgcn_s_setprio(level_); } while (0)
+#define DAVO_PRIO_DOWN(level_) do { if ((level_) > 0) __builtin_amdgcn_s_setprio(0); } while (0)
+
 namespace davo {
 
 constexpr int NCLS = 19;            // Cityscapes train ids (utils/seg_utils/labels.py:64-101)
