@@ -29,6 +29,9 @@
 #define DAVO_F32_ABLATE_A 0    /* timing experiments only: every pixel load reads the zero line / every weight load the first chunk */
 #define DAVO_F32_ABLATE_B 0
 #endif
+#ifndef DAVO_F32_ABLATE_BARRIER
+#define DAVO_F32_ABLATE_BARRIER 0   /* timing experiments only */
+#endif
 
 namespace davo {
 
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         DAVO_PRIO_DOWN(DAVO_MMPRIO);
         __builtin_amdgcn_sched_barrier(0);
         DAVO_STORE_CHUNK(buf ^ 1)
-        __syncthreads();
+        if (!DAVO_F32_ABLATE_BARRIER) __syncthreads();
     }
     DAVO_COMPUTE((q1 - 1 - q0) & 1)
 
