@@ -30,10 +30,12 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from davo_amd.launch import bind_rank_cpus      # noqa: E402  (standard library only)
+BOUND_CPUS = bind_rank_cpus()      # a rank started by davo_amd.launch binds itself to its CPU slice before numpy starts a thread
+
+import numpy as np      # noqa: E402
 
 # FLOPs of one PoseNN pair evaluation at 128x416, SURVEY.md §8a table L (MACs x 2)
 MACS_PER_PAIR_128x416 = 3890085888

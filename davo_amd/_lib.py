@@ -38,12 +38,12 @@ def lib_path(suffix=None):
 LIB_PATH = lib_path()
 
 EXPORTS = (
-    "davo_create", "davo_load_weight", "davo_weights_missing", "davo_forward", "davo_forward_device",
+    "davo_create", "davo_load_weight", "davo_weights_missing", "davo_forward", "davo_forward_device", "davo_submit", "davo_wait", "davo_pending",
     "davo_last_error", "davo_destroy", "davo_device_malloc", "davo_device_free", "davo_memcpy_h2d",
     "davo_memcpy_d2h", "davo_synchronize", "davo_set_stream", "davo_set_inflight", "davo_profile_enable",
     "davo_profile_reset", "davo_profile_entry", "davo_profile_samples", "davo_last_plan", "davo_set_option", "davo_set_precision", "davo_set_impl", "davo_debug_read", "davo_conv2d_same",
     "davo_host_alloc", "davo_host_free", "davo_host_register", "davo_host_unregister", "davo_calibrate", "davo_activation_range", "davo_set_activation_shifts", "davo_range_stats", "davo_range_report",
-    "davo_comm_unique_id", "davo_comm_init", "davo_comm_size", "davo_allgather_poses", "davo_allgather_poses_device",
+    "davo_comm_preload", "davo_comm_unique_id", "davo_comm_init", "davo_comm_size", "davo_allgather_poses", "davo_allgather_poses_device",
     "davo_comm_allreduce", "davo_comm_barrier", "davo_comm_destroy", "davo_plan_layer", "davo_tile_filter_rows",
 )
 COMM_ID_BYTES = 128
@@ -59,7 +59,45 @@ def sources():
            [os.path.join(INCLUDE, "davo_hip.h")]
 
 
-def build(force=False, verbose=False, suffix=None, extra_flags=()):
+LLVM_OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+class PackedF32Error(RuntimeError):
+    """The linked device code holds packed float32 arithmetic (see HIPCC_FLAGS above): the build is refused."""
+
+
+def scan_packed_f32(so_path):
+    """Disassemble every gfx950 code object of a linked library and list the packed float32 arithmetic in it:
+    -> [(kernel, instruction line)].  Part of build(): a library that contains `v_pk_{fma,mul,add}_f32` is not installed, whatever
+    put it there (a compiler upgrade that ignores -fno-slp-vectorize, a builtin, inline asm).  ~5 s."""
+    import re
+    import shutil
+    import tempfile
+    pat = re.compile(r"^\s*v_pk_(fma|mul|add)_f32\b")
+    hits = []
+    d = tempfile.mkdtemp(prefix="davo_isa_")
+    try:
+        tmp = os.path.join(d, "lib.so")
+        shutil.copy(so_path, tmp)
+        subprocess.check_call([LLVM_OBJDUMP, "--offloading", tmp], stdout=subprocess.DEVNULL, cwd=d)     # code objects land beside the input
+        objs = sorted(f for f in os.listdir(d) if "amdgcn" in f)
+        if not objs:
+            raise PackedF32Error("no gfx950 code object found in %s: the packed-float32 scan cannot vouch for it" % so_path)
+        for f in objs:
+            kernel = None
+            out = subprocess.run([LLVM_OBJDUMP, "-d", os.path.join(d, f)], check=True, capture_output=True, text=True).stdout
+            for line in out.splitlines():
+                m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+                if m:
+                    kernel = m.group(1)
+                elif pat.match(line):
+                    hits.append((kernel, line.strip()))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return hits
+
+
+def build(force=False, verbose=False, suffix=None, extra_flags=(), allow_packed_f32=False):
     """hipcc --offload-arch=gfx950 -> davo_amd/libdavo_hip.so (in-tree, so it travels to the GPU box).
     One object per translation unit, compiled in parallel (the f16x3 instantiations dominate), then linked."""
     out = lib_path(suffix)
@@ -86,17 +124,36 @@ def build(force=False, verbose=False, suffix=None, extra_flags=()):
 
     with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_unit, UNITS))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-Wl,-rpath,/opt/rocm/lib"]
+    staged = out + ".unchecked"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", staged] + objs + ["-ldl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    # the guard of DESIGN.md section 4 ("A flaky sum") is part of the build, not of a test: a library with packed float32
+    # arithmetic in its device code is never installed (experiment builds of tools/build_variant.py may ask for it)
+    hits = [] if allow_packed_f32 else scan_packed_f32(staged)
+    if hits:
+        os.remove(staged)
+        raise PackedF32Error("%d packed float32 instruction(s) in the device code, e.g. %s: `%s' - one operand-select form of them "
+                             "miscomputes on gfx950 (DESIGN.md section 4); the library was not installed"
+                             % (len(hits), hits[0][0], hits[0][1]))
+    os.replace(staged, out)
     return out
 
 
 _lib = None
+_lib_lock = __import__("threading").Lock()
 
 
 def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:                      # start-up threads (loader pinning, RCCL preload, the main thread) may all come here first
+        return _load()
+
+
+def _load():
     global _lib
     if _lib is not None:
         return _lib
@@ -110,6 +167,9 @@ def lib():
     L.davo_weights_missing.argtypes = [vp]
     L.davo_forward.argtypes = [vp, i, vp, vp, vp, vp]
     L.davo_forward_device.argtypes = [vp, i, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.davo_submit.argtypes = [vp, i, vp, vp, vp, vp, i]
+    L.davo_wait.argtypes = [vp, i]
+    L.davo_pending.argtypes = [vp]
     L.davo_last_error.argtypes = [vp]
     L.davo_last_error.restype = ctypes.c_char_p
     L.davo_destroy.argtypes = [vp]
@@ -145,6 +205,7 @@ def lib():
     ip = ctypes.POINTER(i)
     L.davo_plan_layer.argtypes = [i, i, i, ip, ip, ip]
     L.davo_tile_filter_rows.argtypes = [i] * 8 + [ip, ip, i, ip]
+    L.davo_comm_preload.argtypes = [ctypes.c_char_p, i]
     L.davo_comm_unique_id.argtypes = [vp, ctypes.c_char_p, i]
     L.davo_comm_init.argtypes = [vp, i, i, vp]
     L.davo_comm_size.argtypes = [vp, ip, ip]

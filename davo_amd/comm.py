@@ -125,6 +125,64 @@ def wait_for_id(path, rank, timeout=180.0, not_before=None):
         time.sleep(0.02)
 
 
+def preload_in_background():
+    """Start loading librccl on a thread of its own (include/davo_hip.h: davo_comm_preload) and return at once: mapping its 573 MB
+    and registering its code objects is most of a second that a rank can spend behind its own imports, weight file and GPU
+    set-up.  -> the thread (nothing needs to join it: the first communicator call waits for the load by itself)."""
+    import threading
+
+    def load():
+        err = ctypes.create_string_buffer(512)
+        _lib.lib().davo_comm_preload(err, 512)          # a failure is reported by the communicator's constructor
+
+    t = threading.Thread(target=load, name="davo-rccl-preload", daemon=True)
+    t.start()
+    return t
+
+
+class PendingComm:
+    """A communicator that is being built on a second thread (``RcclComm.from_env_async``): the id exchange and
+    ``ncclCommInitRank`` - seconds - run while the rank's windows are already on the GPU; the first use (the pose gather) joins."""
+
+    def __init__(self, engine, rank, world, path=None, timeout=180.0):
+        import threading
+        self._comm = self._exc = None
+        self.t_ready = None
+
+        def build():
+            try:
+                self._comm = RcclComm(engine, rank, world, path, timeout)
+            except BaseException as e:                      # noqa: BLE001 - re-raised in the thread that uses the communicator
+                self._exc = e
+            self.t_ready = time.time()
+
+        self._thread = threading.Thread(target=build, name="davo-rccl-init", daemon=True)
+        self._thread.start()
+
+    def get(self):
+        self._thread.join()
+        if self._exc is not None:
+            raise self._exc
+        return self._comm
+
+    def allgather(self, local, n_per_rank=None):
+        return self.get().allgather(local, n_per_rank)
+
+    def allgather_device(self, d_local, n_per_rank, d_all):
+        return self.get().allgather_device(d_local, n_per_rank, d_all)
+
+    def allreduce(self, value, op="max"):
+        return self.get().allreduce(value, op)
+
+    def barrier(self):
+        self.get().barrier()
+
+    def close(self):
+        self._thread.join()
+        if self._comm is not None:
+            self._comm.close()
+
+
 class RcclComm:
     """``ncclCommInitRank`` on the engine's GPU.  Collective: every rank constructs it."""
 
@@ -156,6 +214,12 @@ class RcclComm:
     def from_env(cls, engine):
         rank, _, world = world_from_env()
         return cls(engine, rank, world)
+
+    @classmethod
+    def from_env_async(cls, engine):
+        """-> PendingComm: the communicator is built on a second thread and joined by its first use."""
+        rank, _, world = world_from_env()
+        return PendingComm(engine, rank, world)
 
     def allgather(self, local, n_per_rank=None):
         """local [n,2,6] (n <= n_per_rank; the rank's slot is zero-padded) -> ([world*n_per_rank,2,6], collective ms)."""

@@ -156,6 +156,7 @@ int davo_weights_missing(davo_ctx* c) {
 namespace {
 
 constexpr int RING = RANGE_RING;
+constexpr int FRESH_EVERY = 256;
 
 size_t img_bytes(const davo_ctx* c) { return (size_t)c->H * c->W * 9; }
 size_t flow_bytes(const davo_ctx* c) { return (size_t)c->H * c->W * 8 * sizeof(float); }
@@ -208,7 +209,14 @@ int zero_base_record(davo_ctx* c, hipStream_t s) {
 int freeze_pending_and_reset_ring(davo_ctx* c) {
     for (Ticket& t : c->tickets)
         if (!t.frozen) {
-            memcpy(t.raw, c->h_range + RANGE_WORDS * (1 + t.ring), sizeof t.raw);      // every stream is idle: the mirrors are final
+            // every stream the context knows is idle, so the mirrors are final - unless the batch went out on a caller's stream the
+            // context no longer runs on (davo_set_stream judges its tickets before a switch; this is the belt to those braces)
+            const unsigned* m = c->h_range + RANGE_WORDS * (1 + t.ring);
+            if (__atomic_load_n(&m[RANGE_SEQ], __ATOMIC_ACQUIRE) != t.seq) {
+                HIP_TRY(c, hipStreamSynchronize(t.stream));
+                if (__atomic_load_n(&m[RANGE_SEQ], __ATOMIC_ACQUIRE) != t.seq) return fail(c, DAVO_ERR_HIP, "a batch finished without reporting its range record");
+            }
+            memcpy(t.raw, m, sizeof t.raw);
             t.frozen = true;
         }
     HIP_TRY(c, hipMemset(c->d_range_base + RANGE_WORDS, 0, RANGE_RING * RANGE_WORDS * sizeof(unsigned)));
@@ -267,10 +275,23 @@ int run_judged(davo_ctx* c, const Ticket& b) {
 // A failed verdict: re-issue the batch - as issued if the scales have moved since and now hold it, re-calibrated on itself if
 // not, on the float32 kernels if even that leaves the range (per-layer scales cannot cover e.g. an inf / NaN producing net).
 // Drains every stream first: the re-issue uses slot 0's workspace and the base record.
-int recover_batch(davo_ctx* c, const Ticket& b) {
+// A caller may have handed the batch's pose buffer to a LATER batch since (two alternating buffers, one buffer overwritten every
+// step): the re-issue therefore writes into a pose buffer of the context and is copied to the caller's only if no batch
+// issued after this one targets an overlapping range - the newest writer of a buffer always wins (pose_spans: davo_forward_device).
+bool pose_superseded(const davo_ctx* c, const Ticket& t) {
+    const uintptr_t lo = (uintptr_t)t.pose, hi = lo + (size_t)t.B * 12 * sizeof(float);
+    for (const PoseSpan& sp : c->pose_spans)
+        if (sp.issue > t.issue && sp.lo < hi && lo < sp.hi) return true;
+    return false;
+}
+
+int recover_batch(davo_ctx* c, const Ticket& orig) {
     { int rc = sync_all_slots(c); if (rc) return rc; }
     const std::string verdict = c->err;
     { int rc = freeze_pending_and_reset_ring(c); if (rc) return rc; }       // the failed slot's maximum must go; the scales may move
+    if (!c->d_reissue_pose) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_reissue_pose), (size_t)c->max_batch * 12 * sizeof(float)));
+    Ticket b = orig;
+    b.pose = c->d_reissue_pose;
     activate_slot(c, 0);
     int rc = run_judged(c, b);
     if (rc == DAVO_ERR_RANGE) {
@@ -289,6 +310,9 @@ int recover_batch(davo_ctx* c, const Ticket& b) {
         c->range_report = "float32 kernels for one batch: " + verdict;
     }
     if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!pose_superseded(c, orig))
+        HIP_TRY(c, hipMemcpy(orig.pose, c->d_reissue_pose, (size_t)orig.B * 12 * sizeof(float), hipMemcpyDeviceToDevice));
     ++c->n_reissued;
     c->err.clear();
     return DAVO_OK;
@@ -326,7 +350,12 @@ int judge_front(davo_ctx* c) {
         else if (rc == DAVO_ERR_RANGE && c->opt_auto_range) {
             // the batch's last kernel reached the same verdict on the same record and kept the inputs (prologue.h)
             if (t.snap && raw[RANGE_SNAP] != 1u) rc = fail(c, DAVO_ERR_INVALID, "internal: a batch failed its range verdict but its inputs were not kept");
-            else rc = recover_batch(c, t);
+            else {
+                rc = recover_batch(c, t);
+                // a davo_submit batch: the re-issue rewrote the pose ring entry, its page-locked twin follows (every stream is idle)
+                if (rc == DAVO_OK && t.h_pose && hipMemcpy(t.h_pose, t.pose, (size_t)t.B * 12 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+                    rc = fail(c, DAVO_ERR_HIP, "copying re-issued poses to the host failed");
+            }
         } else if (rc == DAVO_ERR_RANGE && !t.frozen) {
             // no recovery ("auto_range" 0): the slot's running maximum has served its verdict - the next batch starts afresh
             const std::string keep = c->err;
@@ -355,6 +384,15 @@ int judge_all(davo_ctx* c) {
 }
 
 // the batch about to be issued takes ring slot ring_next: judge what still holds it (may re-issue: before the slot rotation)
+// every batch davo_forward_device issues leaves the range of its pose buffer here (pose_superseded); entries no pending ticket can
+// be older than are dropped
+void note_pose_span(davo_ctx* c, const void* d_pose, int B) {
+    ++c->n_issued;
+    const unsigned long long oldest = c->tickets.empty() ? c->n_issued : c->tickets.front().issue;
+    while (!c->pose_spans.empty() && c->pose_spans.front().issue <= oldest) c->pose_spans.pop_front();
+    if (!c->tickets.empty()) c->pose_spans.push_back(PoseSpan{(uintptr_t)d_pose, (uintptr_t)d_pose + (size_t)B * 12 * sizeof(float), c->n_issued});
+}
+
 int ticket_reserve(davo_ctx* c) {
     while (c->ring_busy[c->ring_next]) {
         const int rc = judge_front(c);
@@ -366,13 +404,22 @@ int ticket_reserve(davo_ctx* c) {
 }
 
 // ... the batch's kernels record into the slot's record; its last kernel keeps the inputs there if the record fails
-int ticket_begin(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, bool* snap) {
+int ticket_begin(davo_ctx* c, int B, const void* d_img, const void* d_flow, const void* d_seg, bool* snap, bool own_inputs = false) {
     const int r = c->ring_next;
-    *snap = c->opt_auto_range && !c->opt_stable_inputs;
+    // own_inputs: the batch reads a staging set of the context (davo_submit), which the next batches overwrite whatever the caller declared
+    *snap = c->opt_auto_range && (!c->opt_stable_inputs || own_inputs);
+    if (*snap && (((uintptr_t)d_img | (uintptr_t)d_flow | (uintptr_t)d_seg) & 15)) return fail(c, DAVO_ERR_INVALID, "device input buffers must be 16-byte aligned");
     { int rc = ensure_ring(c, *snap); if (rc) return rc; }
     c->d_range = ring_record(c, r);
     c->range_zero = true;
-    if (*snap && (((uintptr_t)d_img | (uintptr_t)d_flow | (uintptr_t)d_seg) & 15)) return fail(c, DAVO_ERR_INVALID, "device input buffers must be 16-byte aligned");
+    // The records hold RUNNING maxima (params.h): "clamped" is exact per batch, "too small" is judged on everything a slot has stored
+    // since its record was last zeroed.  So that a long stream that never synchronises still notices activations that collapse,
+    // every FRESH_EVERY-th batch starts from a zeroed record (a memset in stream order ahead of the batch's kernels; that batch pays
+    // its first round's atomics, ~0.2 ms, once in FRESH_EVERY batches).
+    if (++c->since_fresh_record >= FRESH_EVERY) {
+        c->since_fresh_record = 0;
+        HIP_TRY(c, hipMemsetAsync(c->d_range, 0, 6 * sizeof(unsigned), c->stream));
+    }
     if (++c->batch_seq == 0) c->batch_seq = 1;
     c->snap_seq_issued = c->batch_seq;
     c->snap = SnapArgs{c->d_range, c->h_range_dev + RANGE_WORDS * (1 + r), c->batch_seq,
@@ -383,7 +430,7 @@ int ticket_begin(davo_ctx* c, int B, const void* d_img, const void* d_flow, cons
     return DAVO_OK;
 }
 
-int ticket_end(davo_ctx* c, int rc, int B, const void* d_img, const void* d_flow, const void* d_seg, void* d_pose, bool snap) {
+int ticket_end(davo_ctx* c, int rc, int B, const void* d_img, const void* d_flow, const void* d_seg, void* d_pose, bool snap, float* h_pose = nullptr) {
     const int r = c->ring_next;
     c->d_range = c->d_range_base;
     c->range_zero = false;
@@ -393,7 +440,7 @@ int ticket_end(davo_ctx* c, int rc, int B, const void* d_img, const void* d_flow
     if (c->last_precision != 1) return DAVO_OK;                                  // float32 kernels (weight guard): no record, no verdict
     Ticket t{};
     t.B = B; t.img = snap ? c->snap_img[r] : d_img; t.flow = snap ? c->snap_flow[r] : d_flow; t.seg = snap ? c->snap_seg[r] : d_seg;
-    t.pose = d_pose; t.ring = r; t.snap = snap; t.seq = c->snap_seq_issued; t.stream = c->stream;
+    t.pose = d_pose; t.ring = r; t.snap = snap; t.seq = c->snap_seq_issued; t.stream = c->stream; t.h_pose = h_pose; t.issue = c->n_issued;
     for (int i = 0; i < 6; ++i) t.shifts[i] = c->act_shift[i];
     c->tickets.push_back(t);
     c->ring_busy[r] = true;
@@ -416,6 +463,12 @@ int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flo
     c->next_slot = (c->next_slot + 1) % c->inflight;
     bool snap = false;
     if (ticketed) { int rc = ticket_begin(c, B, d_img, d_flow, d_seg, &snap); if (rc) return rc; }
+    if (!ticketed && c->pose_spans.size() > 64) {          // float32 batches behind pending f16x3 tickets: bounded
+        const int rc = judge_all(c);
+        if (rc == DAVO_ERR_RANGE) { c->sticky_range_rc = rc; c->sticky_range_err = c->err; }       // "auto_range" 0: reported by the next davo_synchronize
+        else if (rc) return rc;
+    }
+    note_pose_span(c, d_pose, B);
     if (!elapsed_ms) {
         int rc = forward_device(c, B, d_img, d_flow, d_seg, d_pose);
         if (ticketed) rc = ticket_end(c, rc, B, d_img, d_flow, d_seg, d_pose, snap);
@@ -443,11 +496,143 @@ int davo_forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flo
     return rc;
 }
 
+
+// ---- streaming host entry: davo_submit / davo_wait ----------------------------------------------------------------
+// The reference's driver pulls batches through tf.data's prefetch(8B) while the session runs (test_kitti_pose.py:133-145,
+// data_loader.py:321-324): input transfer, compute and result delivery of neighbouring batches overlap.  davo_forward cannot (it
+// returns poses), so the sequence driver uses this pair.  davo_submit rotates through the in-flight slots like
+// davo_forward_device; on the slot's OWN stream it queues the H2D copies of the batch into the slot's staging set, the forward,
+// and the D2H of the poses into a page-locked ring entry.  A stream runs in order, so the staging set is safe to refill without an
+// event, and with two or more slots the copies of batch n+1 run under the kernels of batch n.  (First built with a copy stream
+// and events between it and the slots: each hipEventRecord costs 6 us of host time and a marker on the queue,
+// profiles/r05a_hip_call_cost.log, and the batch-1 loop ran at 134-168 us per window.)  davo_wait / davo_synchronize judge the
+// batch's range ticket (re-issuing it if need be) and only then write the poses into the caller's array.  Inputs, poses and range
+// snapshots of a batch all live in context-owned memory.
+namespace {
+
+int ensure_stream_state(davo_ctx* c, int slot) {
+    if (!c->d_pose_ring[0])
+        for (int k = 0; k < STREAM_POSES; ++k) {
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_pose_ring[k]), (size_t)c->max_batch * 12 * sizeof(float)));
+            HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pose_ring[k]), (size_t)c->max_batch * 12 * sizeof(float), hipHostMallocDefault));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->pose_done[k], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->st_copied[k], hipEventDisableTiming));
+        }
+    if (!c->st_img[slot]) {
+        HIP_TRY(c, hipMalloc(&c->st_img[slot], img_bytes(c) * c->max_batch));
+        HIP_TRY(c, hipMalloc(&c->st_flow[slot], flow_bytes(c) * c->max_batch));
+        HIP_TRY(c, hipMalloc(&c->st_seg[slot], seg_bytes(c) * c->max_batch));
+        // planes the path never reads (flow 2,3; the target frame's label map) are never copied either: defined contents all the same
+        HIP_TRY(c, hipMemset(c->st_flow[slot], 0, flow_bytes(c) * c->max_batch));
+        HIP_TRY(c, hipMemset(c->st_seg[slot], 0, seg_bytes(c) * c->max_batch));
+    }
+    return DAVO_OK;
+}
+
+bool ticket_pending(const davo_ctx* c, unsigned seq) {
+    for (const Ticket& t : c->tickets) if (t.seq == seq) return true;
+    return false;
+}
+
+// the oldest undelivered batch: verdict (and re-issue) first, then its poses go to the caller's array
+int deliver_front(davo_ctx* c) {
+    const StreamJob j = c->jobs.front();
+    c->jobs.pop_front();
+    while (j.ticketed && ticket_pending(c, j.seq)) {
+        const int rc = judge_front(c);
+        if (rc == DAVO_ERR_RANGE && !c->opt_auto_range) {          // "auto_range" 0: reported by the next davo_synchronize; the poses are delivered as they are
+            if (!c->sticky_range_rc) { c->sticky_range_rc = rc; c->sticky_range_err = c->err; }
+        } else if (rc) return rc;
+    }
+    HIP_TRY(c, hipEventSynchronize(c->pose_done[j.pr]));
+    memcpy(j.pose_out, c->h_pose_ring[j.pr], (size_t)j.B * 12 * sizeof(float));
+    return DAVO_OK;
+}
+
+int deliver_all(davo_ctx* c) {
+    while (!c->jobs.empty()) { const int rc = deliver_front(c); if (rc) { c->jobs.clear(); return rc; } }
+    return DAVO_OK;
+}
+
+}  // namespace
+
+int davo_submit(davo_ctx* c, int B, const uint8_t* img, const float* flow, const float* seg, float* pose_out, int hold) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (!img || !flow || !seg || !pose_out) return fail(c, DAVO_ERR_INVALID, "null host pointer");
+    if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
+    if (hold < 0) return fail(c, DAVO_ERR_INVALID, "hold must be >= 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // deliver what has finished (never blocks), and make room in the pose ring (blocks on the oldest batch only when the ring is full)
+    while (!c->jobs.empty() && ((int)c->jobs.size() >= STREAM_POSES || hipEventQuery(c->pose_done[c->jobs.front().pr]) == hipSuccess)) {
+        const int rc = deliver_front(c);
+        if (rc) return rc;
+    }
+    const bool ticketed = c->impl == 0 && c->precision == 1;
+    if (ticketed) { int rc = ticket_reserve(c); if (rc) return rc; }          // may judge - and re-issue - an older batch: before the slot rotation
+    const int slot = c->next_slot, pr = (int)(c->n_submitted % STREAM_POSES);
+    { int rc = ensure_stream_state(c, slot); if (rc) return rc; }
+    activate_slot(c, slot);
+    c->next_slot = (c->next_slot + 1) % c->inflight;
+    hipStream_t s = c->stream;
+    const size_t nb_img = img_bytes(c), nb_flow = flow_bytes(c), nb_seg = seg_bytes(c);
+    // H2D on the slot's stream, in order behind the forward that last read this staging set.  Only what the path reads crosses PCIe:
+    // flow planes 0,1 (davo.py:978-982) and, unless the variant reads the target frame's label map too (-segmask_all-static),
+    // the two source frames' maps (davo.py:998-1004, 1408-1412).
+    HIP_TRY(c, hipMemcpyAsync(c->st_img[slot], img, nb_img * B, hipMemcpyHostToDevice, s));
+    if (B == 1) HIP_TRY(c, hipMemcpyAsync(c->st_flow[slot], flow, nb_flow / 2, hipMemcpyHostToDevice, s));
+    else HIP_TRY(c, hipMemcpy2DAsync(c->st_flow[slot], nb_flow, flow, nb_flow, nb_flow / 2, B, hipMemcpyHostToDevice, s));
+    if (c->v.att_source == 3 || B < 4) HIP_TRY(c, hipMemcpyAsync(c->st_seg[slot], seg, nb_seg * B, hipMemcpyHostToDevice, s));
+    else
+        for (int plane = 0; plane < 3; plane += 2)
+            HIP_TRY(c, hipMemcpy2DAsync((uint8_t*)c->st_seg[slot] + plane * (nb_seg / 3), nb_seg, (const uint8_t*)seg + plane * (nb_seg / 3), nb_seg,
+                                        nb_seg / 3, B, hipMemcpyHostToDevice, s));
+    // the caller keeps a batch's inputs unchanged for `hold` more submits.  With hold >= STREAM_POSES the pose ring already implies it
+    // (a batch is delivered - so its copies are long done - before the eighth submit after it returns): no event then
+    const bool track_copy = hold < STREAM_POSES;
+    if (track_copy) HIP_TRY(c, hipEventRecord(c->st_copied[pr], s));
+
+    bool snap = false;
+    if (ticketed) { int rc = ticket_begin(c, B, c->st_img[slot], c->st_flow[slot], c->st_seg[slot], &snap, true); if (rc) return rc; }
+    ++c->n_issued;                    // (no pose span: a pose ring entry is not reused before its batch has been delivered)
+    int rc = forward_device(c, B, c->st_img[slot], c->st_flow[slot], c->st_seg[slot], c->d_pose_ring[pr]);
+    const unsigned seq = c->snap_seq_issued;
+    bool has_ticket = false;
+    if (ticketed) {
+        const size_t before = c->tickets.size();
+        rc = ticket_end(c, rc, B, c->st_img[slot], c->st_flow[slot], c->st_seg[slot], c->d_pose_ring[pr], snap, c->h_pose_ring[pr]);
+        has_ticket = c->tickets.size() > before;            // (the weight guard's float32 batches get no ticket)
+    } else if (rc == DAVO_OK && c->f32_fallback) ++c->n_f32_batches;
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_pose_ring[pr], c->d_pose_ring[pr], (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(c->pose_done[pr], s));
+    c->jobs.push_back(StreamJob{B, pose_out, pr, has_ticket, seq});
+    c->copy_tracked[pr] = track_copy;
+    ++c->n_submitted;
+    if (track_copy && (unsigned long long)hold < c->n_submitted) {
+        const int q = (int)((c->n_submitted - 1 - hold) % STREAM_POSES);
+        if (c->copy_tracked[q]) HIP_TRY(c, hipEventSynchronize(c->st_copied[q]));
+        // (a batch submitted with hold >= 8 recorded no event: it has been delivered by now if it is 8 or more submits back, and a
+        // caller that lowers `hold` from one call to the next keeps the larger promise for the batches it made it for)
+    }
+    return DAVO_OK;
+}
+
+int davo_wait(davo_ctx* c, int leave_pending) {
+    if (!c) return DAVO_ERR_INVALID;
+    if (leave_pending < 0) return fail(c, DAVO_ERR_INVALID, "leave_pending must be >= 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    while ((int)c->jobs.size() > leave_pending) { const int rc = deliver_front(c); if (rc) return rc; }
+    return DAVO_OK;
+}
+
+int davo_pending(davo_ctx* c) { return c ? (int)c->jobs.size() : DAVO_ERR_INVALID; }
+
 int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, const float* seg, float* pose_out) {
     if (!c) return DAVO_ERR_INVALID;
     if (!img || !flow || !seg || !pose_out) return fail(c, DAVO_ERR_INVALID, "null host pointer");
     if (B < 1 || B > c->max_batch) return fail(c, DAVO_ERR_INVALID, "batch %d outside [1,%d]", B, c->max_batch);
     HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = deliver_all(c); if (rc) return rc; }          // davo_submit batches still under way: delivered first
     { int rc = sync_all_slots(c); if (rc) return rc; }       // the host path owns the single staging buffer set
     activate_slot(c, 0);
     const size_t HW = (size_t)c->H * c->W;
@@ -500,7 +685,7 @@ int davo_forward(davo_ctx* c, int B, const uint8_t* img, const float* flow, cons
     if (rc == DAVO_OK) note_seen(c, raw, c->act_shift);
     if (rc == DAVO_ERR_RANGE && c->opt_auto_range) {
         // the staged copy of the batch is still in HBM: re-issue it whole (recalibrated, or on the float32 kernels)
-        rc = recover_batch(c, [&] { Ticket t{}; t.B = B; t.img = c->s_img; t.flow = c->s_flow; t.seg = c->s_seg; t.pose = c->s_pose; t.ring = -1; t.stream = c->stream; return t; }());
+        rc = recover_batch(c, [&] { Ticket t{}; t.B = B; t.img = c->s_img; t.flow = c->s_flow; t.seg = c->s_seg; t.pose = c->s_pose; t.ring = -1; t.stream = c->stream; t.issue = ~0ull; return t; }());
         if (rc == DAVO_OK) HIP_TRY(c, hipMemcpy(pose_out, c->s_pose, (size_t)B * 12 * sizeof(float), hipMemcpyDeviceToHost));
     }
     return rc;
@@ -571,13 +756,16 @@ void davo_destroy(davo_ctx* c) {
         if (L.d_bh) (void)hipFree(L.d_bh);
     }
     for (auto e : c->copy_done) (void)hipEventDestroy(e);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->read_stream) (void)hipStreamDestroy(c->read_stream);
-    if (c->h_range) (void)hipHostFree(c->h_range);
-    for (int r = 0; r < RANGE_RING; ++r) {
-        for (void* q : {c->snap_img[r], c->snap_flow[r], c->snap_seg[r]}) if (q) (void)hipFree(q);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (int k = 0; k < STREAM_SETS; ++k)
+        for (void* q : {c->st_img[k], c->st_flow[k], c->st_seg[k]}) if (q) (void)hipFree(q);
+    for (int k = 0; k < STREAM_POSES; ++k) {
+        if (c->d_pose_ring[k]) (void)hipFree(c->d_pose_ring[k]);
+        if (c->h_pose_ring[k]) (void)hipHostFree(c->h_pose_ring[k]);
+        if (c->pose_done[k]) (void)hipEventDestroy(c->pose_done[k]);
+        if (c->st_copied[k]) (void)hipEventDestroy(c->st_copied[k]);
     }
-    void* misc[] = {c->d_range_base, c->d_splitk, c->d_pose_tiles, c->d_w1patch, c->d_w2patch, c->d_w3patch, c->d_w1patch_f32, c->d_w2patch_f32, c->d_w3patch_f32, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
+    void* misc[] = {c->d_reissue_pose, c->d_range_base, c->d_splitk, c->d_pose_tiles, c->d_w1patch, c->d_w2patch, c->d_w3patch, c->d_w1patch_f32, c->d_w2patch_f32, c->d_w3patch_f32, c->d_zeros, c->d_wpred, c->d_bpred, c->s_img, c->s_flow, c->s_seg, c->s_pose};
     for (auto p : misc) if (p) (void)hipFree(p);
     for (auto& kv : c->tile_orders) if (kv.second) (void)hipFree(kv.second);
     for (auto& pe : c->prof_entries)
@@ -631,12 +819,18 @@ int davo_synchronize(davo_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
     // f16x3: the batches davo_forward_device issued since the last synchronize are judged here (the asynchronous
     // entry point cannot know its own result).  A failed verdict re-issues that batch (recover_batch); with "auto_range" 0
-    // it is returned as DAVO_ERR_RANGE = some layer left the fp16-pair storage range
+    // it is returned as DAVO_ERR_RANGE = some layer left the fp16-pair storage range.  davo_submit batches are delivered first.
+    { int rc = deliver_all(c); if (rc) return rc; }
     return judge_all(c);
 }
 int davo_set_stream(davo_ctx* c, void* hip_stream) {
     if (!c) return DAVO_ERR_INVALID;
     if (hip_stream && c->inflight > 1) return fail(c, DAVO_ERR_INVALID, "a caller-owned stream needs davo_set_inflight(ctx, 1)");
+    // batches issued on the stream the context is about to leave get their verdict (and any re-issue) while that stream is still
+    // the one the context synchronises; the caller may destroy it afterwards
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = deliver_all(c); if (rc) return rc; }
+    { int rc = judge_all(c); if (rc) return rc; }
     c->user_stream = hip_stream != nullptr;
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
     return DAVO_OK;
@@ -717,6 +911,7 @@ int davo_set_inflight(davo_ctx* c, int n) {
     if (!c || n < 1 || n > 4) return fail(c, DAVO_ERR_INVALID, "inflight must be 1..4");
     if (n > 1 && c->user_stream) return fail(c, DAVO_ERR_INVALID, "in-flight slots use the context's own streams: clear davo_set_stream first");
     HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = deliver_all(c); if (rc) return rc; }
     { int rc = sync_all_slots(c); if (rc) return rc; }
     while ((int)c->slots.size() < n) {
         c->slots.emplace_back();

@@ -119,6 +119,13 @@ using namespace davo;
 
 extern "C" {
 
+int davo_comm_preload(char* err, int err_len) {
+    std::string why;
+    if (rccl(&why)) return DAVO_OK;
+    if (err && err_len > 0) { strncpy(err, ("librccl could not be loaded: " + why).c_str(), err_len - 1); err[err_len - 1] = 0; }
+    return DAVO_ERR_COMM;
+}
+
 int davo_comm_unique_id(void* id_out, char* err, int err_len) {
     auto bad = [&](const std::string& m, int code) {
         if (err && err_len > 0) { strncpy(err, m.c_str(), err_len - 1); err[err_len - 1] = 0; }
@@ -143,26 +150,28 @@ int davo_comm_init(davo_ctx* c, int nranks, int rank, const void* id) {
     std::string why;
     Rccl* R = rccl(&why);
     if (!R) return fail(c, DAVO_ERR_COMM, "librccl could not be loaded: %s", why.c_str());
-    HIP_TRY(c, hipSetDevice(c->device));
+    // Built aside and published last: this call takes seconds (library load, bootstrap, topology) and a host may run it on a
+    // second thread while the context's owner thread issues forwards (davo_hip.h) - until the last line it touches the context
+    // only to report a failure.
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, DAVO_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     Comm* m = new Comm();
-    c->comm = m;
     m->nranks = nranks; m->rank = rank;
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
-    {
-        const ncclResult_t r = R->CommInitRank(&m->comm, nranks, uid, rank);
-        if (r != ncclSuccess) {
-            m->comm = nullptr;
-            const int rc = fail(c, DAVO_ERR_COMM, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, nranks, c->device, R->GetErrorString(r));
-            const std::string keep = c->err;
-            comm_release(c);
-            c->err = keep;
-            return rc;
-        }
+    const ncclResult_t r = R->CommInitRank(&m->comm, nranks, uid, rank);
+    if (r != ncclSuccess) {
+        delete m;
+        return fail(c, DAVO_ERR_COMM, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, nranks, c->device, R->GetErrorString(r));
     }
-    HIP_TRY(c, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipEventCreate(&m->e0));
-    HIP_TRY(c, hipEventCreate(&m->e1));
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->e0) != hipSuccess ||
+        hipEventCreate(&m->e1) != hipSuccess) {
+        (void)R->CommDestroy(m->comm);
+        if (m->stream) (void)hipStreamDestroy(m->stream);
+        if (m->e0) (void)hipEventDestroy(m->e0);
+        delete m;
+        return fail(c, DAVO_ERR_HIP, "creating the communicator's stream and events failed");
+    }
+    c->comm = m;
     return DAVO_OK;
 }
 

@@ -83,7 +83,23 @@ struct Ticket {
     unsigned seq;                              // the batch's sequence number: its last kernel writes it into the slot's host mirror
     hipStream_t stream;                        // the stream it was issued on
     int shifts[6];                             // storage scales the batch was issued under (davo_activation_range reports true magnitudes)
+    unsigned long long issue;                  // issue number of the batch (pose_superseded, api.hip)
+    float* h_pose;                             // davo_submit batches: page-locked host copy of `pose`, refreshed after a re-issue (else null)
 };
+
+// A batch davo_submit has issued whose poses have not been delivered to the caller's array yet (api.hip: streaming entry point).
+// Its inputs live in the staging set of its in-flight slot (at most STREAM_SETS slots), its poses in entry `pr` of a ring of STREAM_POSES device
+// buffers with page-locked host twins, so neither a re-issue nor the caller's buffer recycling can touch another batch's data.
+constexpr int STREAM_SETS = 4, STREAM_POSES = 8;
+struct StreamJob {
+    int B;
+    float* pose_out;                           // the caller's [B,2,6] (pageable is fine: written by the host at delivery)
+    int pr;                                    // pose ring entry
+    bool ticketed;                             // has a range ticket (f16x3) that must be judged before delivery
+    unsigned seq;                              // ... its sequence number
+};
+
+struct PoseSpan { uintptr_t lo, hi; unsigned long long issue; };      // the pose buffer range of an issued batch (api.hip: pose_superseded)
 
 struct Comm;                                     // comm.hip: RCCL communicator state
 
@@ -180,6 +196,18 @@ struct davo_ctx {
     std::string range_report;                  // what the range management last did, in words (davo_range_report)
     long long n_recalibrations = 0, n_f32_batches = 0, n_reissued = 0;
     int host_chunk = 8;                        // davo_forward: windows per sub-batch (davo_set_option "host_chunk"; 0 = whole batch)
+    // streaming host entry (davo_submit / davo_wait): staging input sets, pose ring, undelivered batches in issue order
+    void *st_img[davo::STREAM_SETS] = {}, *st_flow[davo::STREAM_SETS] = {}, *st_seg[davo::STREAM_SETS] = {};     // one staging set per in-flight slot
+    hipEvent_t st_copied[davo::STREAM_POSES] = {};             // "the H2D copies of the batch in pose ring entry k are done" (recorded only for hold < STREAM_POSES)
+    bool copy_tracked[davo::STREAM_POSES] = {};
+    float *d_pose_ring[davo::STREAM_POSES] = {}, *h_pose_ring[davo::STREAM_POSES] = {};
+    hipEvent_t pose_done[davo::STREAM_POSES] = {};
+    std::deque<davo::StreamJob> jobs;
+    unsigned long long n_submitted = 0;
+    float* d_reissue_pose = nullptr;           // a re-issued batch writes here first; copied to its own pose buffer unless a later batch has taken that
+    std::deque<davo::PoseSpan> pose_spans;     // pose buffer ranges of the batches issued since the oldest pending ticket
+    unsigned long long n_issued = 0;
+    int since_fresh_record = 0;                // ticketed batches since one last started from a zeroed range record (api.hip: ticket_begin)
     // profiling
     bool prof = false;
     bool prof_dominant_only = false;           // profile mode 2: bracket only the main cnv6 launch

@@ -148,6 +148,42 @@ class Engine:
                                          seg.ctypes.data_as(vp), out.ctypes.data_as(vp)))
         return out
 
+    def _check_batch(self, img, flow, seg):
+        B = img.shape[0]
+        if img.shape != (B, self.H, 3 * self.W, 3):
+            raise ValueError("img shape %s != %s" % (img.shape, (B, self.H, 3 * self.W, 3)))
+        if flow.shape != (B, 4, self.H, self.W, 2):
+            raise ValueError("flow shape %s != %s" % (flow.shape, (B, 4, self.H, self.W, 2)))
+        if seg.shape != (B, 3, self.H, self.W, 1):
+            raise ValueError("seg shape %s != %s" % (seg.shape, (B, 3, self.H, self.W, 1)))
+        return B
+
+    def submit(self, img, flow, seg, out, hold=0):
+        """Streaming form of forward (include/davo_hip.h: davo_submit): issue the batch and return; ``out`` - a C-contiguous
+        float32 [B,2,6] array the caller keeps alive - receives the poses when the batch is delivered (a later submit, wait()
+        or synchronize()).  On return the input arrays of the batch submitted ``hold`` calls ago may be overwritten."""
+        if not (isinstance(img, np.ndarray) and img.dtype == np.uint8 and img.flags.c_contiguous and
+                isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.flags.c_contiguous and
+                isinstance(seg, np.ndarray) and seg.dtype == np.float32 and seg.flags.c_contiguous):
+            if hold:
+                raise ValueError("submit(hold > 0) needs C-contiguous uint8 / float32 / float32 arrays (a converted copy would not outlive the call)")
+            img = np.ascontiguousarray(img, np.uint8)
+            flow = np.ascontiguousarray(flow, np.float32)
+            seg = np.ascontiguousarray(seg, np.float32)
+        B = self._check_batch(img, flow, seg)
+        if not (isinstance(out, np.ndarray) and out.dtype == np.float32 and out.flags.c_contiguous and out.shape == (B, 2, 6)):
+            raise ValueError("out must be a C-contiguous float32 array of shape (%d, 2, 6)" % B)
+        vp = ctypes.c_void_p
+        self._check(self._L.davo_submit(self._ctx, B, img.ctypes.data_as(vp), flow.ctypes.data_as(vp), seg.ctypes.data_as(vp),
+                                        out.ctypes.data_as(vp), int(hold)))
+
+    def wait(self, leave_pending=0):
+        """Deliver submitted batches until at most ``leave_pending`` are outstanding (include/davo_hip.h: davo_wait)."""
+        self._check(self._L.davo_wait(self._ctx, int(leave_pending)))
+
+    def pending(self):
+        return self._L.davo_pending(self._ctx)
+
     LAYERS = ("cnv1", "cnv2", "cnv3", "cnv4", "cnv5", "cnv6")
 
     def calibrate(self, img, flow, seg):
@@ -313,8 +349,13 @@ class DAVO(object):
         self.engine = Engine(self.cfg, img_height, img_width, batch_size, self.device)
         if self._weights is not None:
             self.engine.load_weights(self._weights)
+        self._ahead = []                                   # iterator inputs: batches submitted and not returned yet
         if input_img_uint8 is not None and not isinstance(input_img_uint8, np.ndarray) and input_flow is None:
             self._inputs = iter(input_img_uint8)
+            # the counterpart of the tf.data iterator the reference's graph pulls from (data_loader.py:321-324, prefetch): batches
+            # go through the library's streaming entry point, so while inference() call n waits for its poses, batch n+1 is
+            # already copied and running (two in flight on the GPU)
+            self.engine.set_inflight(2)
         else:
             self._inputs = (input_img_uint8, input_flow, input_seglabel)
 
@@ -338,12 +379,29 @@ class DAVO(object):
             raise NotImplementedError("mode `%s': only 'pose' is built (davo.py:1555-1556)" % mode)
         if self.engine is None:
             raise DavoError("setup_inference(..., mode='davo') has not been called")
+        if inputs is None and not isinstance(self._inputs, tuple):
+            return {'pose': self._next_from_iterator()}
         if inputs is not None:
             img, flow, seg = inputs
-        elif isinstance(self._inputs, tuple):
-            img, flow, seg = self._inputs
         else:
-            img, flow, seg = next(self._inputs)
+            img, flow, seg = self._inputs
         if img is None or flow is None or seg is None:
             raise ValueError("image, flow and seglabel inputs are all required for version `%s'" % self.version)
         return {'pose': self.engine.forward(img, flow, seg)}
+
+    def _next_from_iterator(self):
+        """Poses of the iterator's next batch; the batch after it is submitted before this one is waited for.  A batch the
+        iterator yields must stay valid until the iterator is asked for the next one (davo_amd.loader's contract)."""
+        while len(self._ahead) < 2:
+            item = next(self._inputs, None)
+            if item is None:
+                break
+            img, flow, seg = item
+            out = np.empty((np.shape(img)[0], 2, 6), np.float32)
+            self.engine.submit(img, flow, seg, out)             # hold = 0: the batch is copied when this returns
+            self._ahead.append(out)
+        if not self._ahead:
+            raise StopIteration("the input iterator is exhausted")      # tf.errors.OutOfRangeError's counterpart
+        out = self._ahead.pop(0)
+        self.engine.wait(len(self._ahead))
+        return out

@@ -8,9 +8,12 @@ parent only waits: it returns the first non-zero exit code and stops the remaini
 rank fails the run (no rank is left waiting in a collective).  Nothing here imports the HIP library
 or initialises a device — a process that has done so must not be replaced or forked into ranks.
 
-Each rank is bound to its own contiguous slice of the CPUs this process may use (``sched_getaffinity``), so the
-ranks' loader / decode threads do not migrate over each other's cores (and stay on one NUMA side where the
-allowed set spans several).  ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is passed on (and defaulted) because RCCL shares device
+Each rank is given its own contiguous slice of the CPUs this process may use (``sched_getaffinity``) in ``DAVO_CPU_SLICE``
+and binds ITSELF to it in its first statements (``bind_rank_cpus``: the top of ``davo_amd/__init__.py`` and of ``bench.py``,
+before numpy or the HIP library start a thread), so the ranks' loader / decode threads do not migrate over each other's cores
+(and stay on one NUMA side where the allowed set spans several).  No process here ever replaces its own program: an ``exec``
+from a process that a preloaded library (``rocprofv3 -- python bench.py --gpus N``) has already made a GPU process takes the
+machine down on this pool.  ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is passed on (and defaulted) because RCCL shares device
 buffers between the ranks' processes through HIP IPC handles, and the hosts' driver only supports the dmabuf form of
 them: with the legacy mode ``ncclCommInitRank`` fails in ``hipIpcGetMemHandle: invalid argument``.
 """
@@ -24,12 +27,22 @@ import tempfile
 import time
 
 
-_BIND_AND_EXEC = ("import os, sys\n"
-                  "try:\n"
-                  "    os.sched_setaffinity(0, {int(c) for c in sys.argv[1].split(',')})\n"
-                  "except OSError:\n"
-                  "    pass\n"
-                  "os.execv(sys.argv[2], sys.argv[2:])\n")
+CPU_SLICE_ENV = "DAVO_CPU_SLICE"
+
+
+def bind_rank_cpus(environ=None):
+    """A rank's first statement: bind this process to the CPU slice its launcher chose (``DAVO_CPU_SLICE``: comma-separated
+    CPU numbers), before anything has started a thread - every thread and worker process the rank ever starts inherits it.
+    Returns the set it bound to, or None (variable unset or empty, or the kernel refused).  Needs nothing but ``os``."""
+    spec = (os.environ if environ is None else environ).get(CPU_SLICE_ENV, "")
+    if not spec:
+        return None
+    try:
+        cpus = {int(c) for c in spec.split(",")}
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_slices(nprocs, cpus=None):
@@ -58,10 +71,12 @@ def spawn_ranks(argv, nprocs, env_extra=None, timeout=None, bind_cpus=True, stdo
                 env.update(env_extra)
             cmd = [sys.executable] + list(argv)
             if slices is not None:
-                # the rank binds ITSELF, in a bare interpreter that has imported nothing and started no thread, and then becomes
-                # the real command (exec before anything touches a GPU): every thread the rank ever starts inherits the slice.
-                # (Setting the affinity of p.pid from here after Popen raced with the child's first threads: ADVICE r3.)
-                cmd = [sys.executable, "-c", _BIND_AND_EXEC, ",".join(str(c) for c in sorted(slices[r]))] + cmd
+                # the rank binds itself in its first statements (bind_rank_cpus).  Setting the affinity of p.pid from here after
+                # Popen raced with the child's first threads; a bare interpreter that bound itself and then exec'ed the
+                # command was one program replacement too many on this pool (ADVICE / VERDICT r4)
+                env[CPU_SLICE_ENV] = ",".join(str(c) for c in sorted(slices[r]))
+            else:
+                env.pop(CPU_SLICE_ENV, None)
             procs.append(subprocess.Popen(cmd, env=env, stdout=stdout))
         t0 = time.time()
         code = 0

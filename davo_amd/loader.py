@@ -250,30 +250,93 @@ def shm_budget_bytes():
     return int(min(free // 4, 2 << 30))
 
 
-def _proc_init(names, B, H, W, dump_dir, seq, flow_planes, seg_planes):
+def _keep_freed_memory_mapped():
+    """A window's decode allocates and frees the strip four times over (Pillow's image core, the RGB copy, its bytes, the array:
+    480 KB each).  In a worker forked from the fresh fork server glibc serves each of them by mmap and returns it by munmap, so
+    every window pays ~470 minor faults on brand-new zero pages (177 k faults per worker and run, 546 per window, measured:
+    profiles/r05d_loader_diag2.log) and a worker needs 1.16 ms per window where the same loop in a process whose allocator has
+    already learnt to keep such blocks needs 0.66.  Tell the allocator up front: blocks up to 32 MB come from the heap, and the heap
+    is not trimmed."""
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 32 << 20)            # M_MMAP_THRESHOLD (glibc's maximum)
+        libc.mallopt(-1, 1 << 30)             # M_TRIM_THRESHOLD
+        libc.mallopt(-2, 16 << 20)            # M_TOP_PAD
+    except (OSError, AttributeError):
+        pass                                  # another libc: slower, not wrong
+
+
+def _chunk_owner(c, chunks_per_ring, P):
+    """Worker that fills chunk c.  A chunk's place in the ring of batch buffers is c % chunks_per_ring and that place is always
+    filled by the same worker, so a worker only ever writes its own pages of the shared buffers: its first touch of a page (a minor
+    fault per page and process although the page exists) happens once, in the first trip round the ring, not on every window."""
+    return (c % chunks_per_ring) % P
+
+
+def _slot_worker(k, P, names, ctrl_name, B, H, W, dump_dir, seq, flow_planes, seg_planes, lo, hi, chunk, nring, sem, errq):
+    """Worker k of P (a fork of the warm fork server): fills its chunks of windows [lo, hi) in order, straight into the shared batch
+    buffers.  No task queue: which chunks are its own follows from k (_chunk_owner); ctrl[0] = number of batches that may be filled
+    (the consumer's progress + the ring), ctrl[1] = stop, ctrl[2 + k] = chunks this worker has finished, ctrl[2 + P + k] = ns it
+    worked.  One semaphore post per finished chunk wakes the consumer."""
+    import time
     from multiprocessing import shared_memory
-    ring = []
-    for trio in names:
-        # spawned workers report to the parent's resource tracker, where these names are registered already (a set): attaching
-        # changes nothing there, and the parent's close() is what unlinks the segments
-        segs = [shared_memory.SharedMemory(name=n) for n in trio]
-        ring.append((segs, (np.ndarray((B, H, 3 * W, 3), np.uint8, buffer=segs[0].buf),
-                            np.ndarray((B, 4, H, W, 2), np.float32, buffer=segs[1].buf),
-                            np.ndarray((B, 3, H, W, 1), np.float32, buffer=segs[2].buf))))
-    _W.update(ring=ring, dump=dump_dir, seq=seq, H=H, W=W, fp=flow_planes, sp=seg_planes)
-
-
-def _proc_ready():
-    return os.getpid()
-
-
-def _proc_fill(ring_idx, slot0, w0, n):
-    """windows w0 .. w0+n-1 (target frames w+1) into slots slot0.. of buffer set ring_idx; returns n"""
-    img, flow, seg = _W["ring"][ring_idx][1]
-    for j in range(n):
-        load_window_into(_W["dump"], _W["seq"], w0 + j + 1, _W["H"], _W["W"], img[slot0 + j], flow[slot0 + j], seg[slot0 + j],
-                         None, _W["fp"], _W["sp"])
-    return n
+    _keep_freed_memory_mapped()
+    ctrl_shm = shared_memory.SharedMemory(name=ctrl_name)
+    ctrl = np.ndarray((2 + 2 * P,), np.int64, buffer=ctrl_shm.buf)
+    segs = []
+    try:
+        ring = []
+        for trio in names:
+            # the names are registered with the parent's resource tracker already; the parent's close() is what unlinks them
+            t = [shared_memory.SharedMemory(name=n) for n in trio]
+            segs += t
+            ring.append((np.ndarray((B, H, 3 * W, 3), np.uint8, buffer=t[0].buf), np.ndarray((B, 4, H, W, 2), np.float32, buffer=t[1].buf),
+                         np.ndarray((B, 3, H, W, 1), np.float32, buffer=t[2].buf)))
+        cpb = -(-B // chunk)                               # chunks per batch (the last one of a batch may be short)
+        nbatches = -(-(hi - lo) // B)
+        for c in range(nbatches * cpb):
+            if _chunk_owner(c, cpb * nring, P) != k:
+                continue
+            bi, j = divmod(c, cpb)
+            w0 = lo + bi * B + j * chunk
+            w1 = min(w0 + chunk, lo + bi * B + B, hi)
+            if w0 < w1:
+                while ctrl[0] <= bi:                       # the ring entry still holds a batch the consumer has not released
+                    if ctrl[1]:
+                        return
+                    time.sleep(0.0002)
+                if ctrl[1]:
+                    return
+                t0 = time.perf_counter_ns()
+                img, flow, seg = ring[bi % nring]
+                for w in range(w0, w1):
+                    i = w - lo - bi * B
+                    load_window_into(dump_dir, seq, w + 1, H, W, img[i], flow[i], seg[i], None, flow_planes, seg_planes)
+                ctrl[2 + P + k] += time.perf_counter_ns() - t0
+            ctrl[2 + k] += 1
+            sem.release()
+        if os.environ.get("DAVO_LOADER_DIAG"):             # measurement aid (tools/exp/loader_breakdown.py): where this worker's time went
+            import resource
+            import sys
+            r = resource.getrusage(resource.RUSAGE_SELF)
+            sys.stderr.write("loader worker %2d: busy %.3f s wall, %.3f s cpu in total, %d minor faults, %d voluntary / %d involuntary context "
+                             "switches, cpu %s\n" % (k, ctrl[2 + P + k] * 1e-9, time.process_time(), r.ru_minflt, r.ru_nvcsw, r.ru_nivcsw,
+                                                     open("/proc/self/stat").read().rsplit(")", 1)[1].split()[36]))
+    except BaseException as exc:                           # noqa: BLE001 - hand the failure to the consumer
+        try:
+            errq.put(exc)
+        except Exception:                                  # noqa: BLE001 - an exception that does not pickle
+            errq.put(RuntimeError("loader worker %d: %r" % (k, exc)))
+        ctrl[1] = 1
+        sem.release()
+    finally:
+        del ctrl
+        for sm in segs + [ctrl_shm]:
+            try:
+                sm.close()
+            except (OSError, BufferError):
+                pass
 
 
 class ShmBudgetError(RuntimeError):
@@ -284,39 +347,46 @@ class ProcessWindowLoader:
     """Batches of windows [lo, hi) in order, filled by ``procs`` worker PROCESSES that decode the strip and read the
     .npy planes of whole windows straight into shared-memory batch buffers (data_loader.py:241-325's pipeline with
     processes where TF has native threads: Pillow decodes under the GIL, so threads give one core's worth of JPEG).
-    The parent never touches a pixel: it hands out (buffer set, slot range, window range) tasks of ``chunk`` windows
-    and yields a batch when its tasks are done.  ``pin(array)`` / ``unpin(array)`` page-lock the buffers for the H2D DMA
-    (davo_amd.pin_array: hipHostRegister over the shared mapping).  Only the flow planes and label maps the variant
-    consumes are read; the rest of a slot keeps its zeros.  Workers are forks of a warm fork server (worker_context): the
-    parent may hold a HIP context, the server never does.
+    The parent never touches a pixel and runs no task queue: every worker knows which chunks of ``chunk`` windows are its own
+    (``_chunk_owner``: always the same places of the ring, so it writes only pages it has touched before), fills them in order as
+    far as the consumer's progress allows, and counts them in a small shared control block; the consumer yields a batch when the
+    counts say its chunks are done.  (Round 3/4 handed chunks out through a ProcessPoolExecutor: a worker then met every page of
+    every buffer for the first time sooner or later - 460 minor faults per window - and needed 1.3 ms per window where a plain
+    process needs 0.66: 12.3 k windows/s on 14 workers against 20.6 k, profiles/r05b_loader_breakdown.log, r05c_loader_diag.log.)
+    ``pin(array)`` / ``unpin(array)`` page-lock the buffers for the H2D DMA (davo_amd.pin_array: hipHostRegister over the shared
+    mapping).  Only the flow planes and label maps the variant consumes are read; the rest of a slot keeps its zeros.  Workers
+    are forks of a warm fork server (worker_context): the parent may hold a HIP context, the server never does.
 
-    A batch is valid until the consumer asks for the next one; the last one until ``close()`` (or the loader's deletion),
-    which unpins and unmaps the buffers.  The end of iteration stops the workers and removes the segments' names."""
+    A batch is valid until the consumer has asked for ``hold`` + 1 further ones (``hold`` = 0: until the next one); the last
+    ones until ``close()`` (or the loader's deletion), which unpins and unmaps the buffers.  The end of iteration stops the
+    workers and removes the segments' names."""
 
     def __init__(self, dump_dir, seq, H, W, lo, hi, batch_size, procs=8, prefetch=2, chunk=None, pin=None, unpin=None,
-                 flow_planes=FLOW_PLANES_USED, seg_planes=SEG_PLANES_SOURCES, shm_budget=None):
+                 flow_planes=FLOW_PLANES_USED, seg_planes=SEG_PLANES_SOURCES, shm_budget=None, hold=0):
         self.args = (dump_dir, seq, H, W)
         self.lo, self.hi, self.B = lo, hi, batch_size
-        self.procs, self.prefetch = max(1, procs), max(1, prefetch)
-        self.chunk = chunk or max(1, min(4, batch_size))
-        # batches being filled at once: enough windows in flight (three tasks per worker) that no worker idles at a batch's end
+        self.procs, self.prefetch, self.hold = max(1, procs), max(1, prefetch), max(0, hold)
+        self.chunk = max(1, min(chunk or 4, batch_size))
+        # batches being filled at once: enough windows in flight (three chunks per worker) that no worker idles at a batch's end
         self.fill = max(2, -(-3 * self.procs * self.chunk // batch_size))
-        # the ring is sized in BYTES: prefetch + fill + 2 batch buffer trios if they fit the budget (shm_budget_bytes), fewer
-        # batches in flight if not, and a clear error - the caller falls back to the threaded loader - if not even three fit
+        # the ring is sized in BYTES: prefetch + fill + 2 (+ hold) batch buffer trios if they fit the budget (shm_budget_bytes),
+        # fewer batches in flight if not, and a clear error - the caller falls back to the threaded loader - if not even four fit
         per_batch = batch_size * (H * 3 * W * 3 + 4 * H * W * 2 * 4 + 3 * H * W * 4)
         budget = shm_budget_bytes() if shm_budget is None else shm_budget
-        want = self.prefetch + self.fill + 2
+        want = self.prefetch + self.fill + 2 + self.hold
         self.nring = min(want, budget // per_batch)
-        if self.nring < 4:            # one being filled, one queued, one waiting in q.put, one with the consumer
-            raise ShmBudgetError("batch buffers of %.0f MB each do not fit /dev/shm's budget of %.0f MB four times "
+        if self.nring < 4 + self.hold:     # one being filled, two ready / in flight, one (+ hold) with the consumer
+            raise ShmBudgetError("batch buffers of %.0f MB each do not fit /dev/shm's budget of %.0f MB %d times "
                                  "(ProcessWindowLoader needs shared memory: use the threaded loader, --loader_procs 0)"
-                                 % (per_batch / 2 ** 20, budget / 2 ** 20))
+                                 % (per_batch / 2 ** 20, budget / 2 ** 20, 4 + self.hold))
         if self.nring < want:
-            self.fill = max(1, self.nring - 3)
-            self.prefetch = self.nring - 2 - self.fill
+            self.fill = max(1, self.nring - 3 - self.hold)
+            self.prefetch = self.nring - 2 - self.fill - self.hold
         self.pin, self.unpin, self.fp, self.sp = pin, unpin, flow_planes, seg_planes
         self._segs, self._views, self._pool, self._pinned, self._unlinked = [], [], None, [], []
-        self._thread = self._q = self._stop_evt = None
+        self._ctrl_shm = self._ctrl = self._sem = self._errq = None
+        self._started = False
+        self.busy_s = 0.0
 
     def __len__(self):
         return -(-(self.hi - self.lo) // self.B)
@@ -325,7 +395,7 @@ class ProcessWindowLoader:
         self.close()                                      # a second iteration starts from fresh buffers
         from multiprocessing import shared_memory
         dump_dir, seq, H, W = self.args
-        B = self.B
+        B, P = self.B, self.procs
         sizes = (B * H * 3 * W * 3, B * 4 * H * W * 2 * 4, B * 3 * H * W * 4)
         for _ in range(self.nring):
             trio = [shared_memory.SharedMemory(create=True, size=max(n, 1)) for n in sizes]
@@ -338,47 +408,50 @@ class ProcessWindowLoader:
                 for v in views:
                     self.pin(v)
                     self._pinned.append(v)
+        self._ctrl_shm = shared_memory.SharedMemory(create=True, size=8 * (2 + 2 * P))
+        self._ctrl = np.ndarray((2 + 2 * P,), np.int64, buffer=self._ctrl_shm.buf)
+        self._ctrl[:] = 0
+        self._ctrl[0] = self.nring                        # nothing is with the consumer yet: every ring entry may be filled
         names = [[sm.name for sm in trio] for trio in self._segs]
-        self._pool = ProcessPoolExecutor(self.procs, mp_context=worker_context(), initializer=_proc_init,
-                                         initargs=(names, B, H, W, dump_dir, seq, self.fp, self.sp))
-        # ProcessPoolExecutor starts its workers lazily, one per submitted task: ask for all of them now, so that they fork
-        # (and attach the buffers) while the caller is still setting up
-        for f in [self._pool.submit(_proc_ready) for _ in range(self.procs)]:
-            f.add_done_callback(lambda _f: None)
+        ctx = worker_context()
+        self._sem, self._errq = ctx.Semaphore(0), ctx.SimpleQueue()
+        self._pool = [ctx.Process(target=_slot_worker, daemon=True,
+                                  args=(k, P, names, self._ctrl_shm.name, B, H, W, dump_dir, seq, self.fp, self.sp, self.lo, self.hi,
+                                        self.chunk, self.nring, self._sem, self._errq)) for k in range(P)]
+        for p in self._pool:                              # forks of the warm server: they attach the buffers and start filling at once
+            p.start()
+        # what batch bi needs: per worker, the number of its chunks among the chunks of batches 0..bi (its chunks run in order)
+        self._cpb = -(-B // self.chunk)
+        self._need = np.zeros(P, np.int64)
+        self._need_upto = 0                               # chunks counted into _need so far
 
     def _stop(self):
-        """end of iteration: no more tasks; the names leave /dev/shm (nothing leaks if the process dies from here on) while
-        the mappings - and with them the last batch the consumer may still hold - stay valid until close()"""
+        """end of iteration: the workers stop; the names leave /dev/shm (nothing leaks if the process dies from here on) while
+        the mappings - and with them the last batches the consumer may still hold - stay valid until close()"""
         if self._pool is not None:
-            self._pool.shutdown(wait=True, cancel_futures=True)
+            if self._ctrl is not None:
+                self.busy_s = float(self._ctrl[2 + self.procs:2 + 2 * self.procs].sum()) * 1e-9
+                self._ctrl[1] = 1
+            for p in self._pool:
+                p.join(timeout=5.0)
+            for p in self._pool:
+                if p.is_alive():
+                    p.terminate()
+                    p.join(timeout=1.0)
             self._pool = None
-        for trio in self._segs:
-            for sm in trio:
-                if sm not in self._unlinked:
-                    self._unlinked.append(sm)
-                    try:
-                        sm.unlink()
-                    except OSError:
-                        pass
-
-    def _halt(self):
-        """a loader that was started but never (or not fully) iterated: stop its producer before the buffers go away"""
-        t = self._thread
-        if t is not None:
-            self._stop_evt.set()
-            while t.is_alive():
+        for sm in [sm for trio in self._segs for sm in trio] + ([self._ctrl_shm] if self._ctrl_shm is not None else []):
+            if sm not in self._unlinked:
+                self._unlinked.append(sm)
                 try:
-                    self._q.get_nowait()
-                except queue.Empty:
+                    sm.unlink()
+                except OSError:
                     pass
-                t.join(timeout=0.05)
-            self._thread = None
 
     def close(self):
         """unpin and unmap the batch buffers: every array this loader has yielded is invalid afterwards (numpy does not keep
         a shared-memory mapping alive).  Called by __del__; iteration itself only stops the workers (_stop)."""
-        self._halt()
         self._stop()
+        self._started = False
         if self.unpin is not None:
             for v in self._pinned:
                 try:
@@ -387,13 +460,13 @@ class ProcessWindowLoader:
                     pass
         self._pinned = []
         self._views = []
-        for trio in self._segs:
-            for sm in trio:
-                try:
-                    sm.close()
-                except (OSError, BufferError):
-                    pass
-        self._segs, self._unlinked = [], []
+        self._ctrl = None
+        for sm in [sm for trio in self._segs for sm in trio] + ([self._ctrl_shm] if self._ctrl_shm is not None else []):
+            try:
+                sm.close()
+            except (OSError, BufferError):
+                pass
+        self._segs, self._unlinked, self._ctrl_shm = [], [], None
 
     def __del__(self):
         try:
@@ -402,69 +475,44 @@ class ProcessWindowLoader:
             pass
 
     def start(self):
-        """Create the buffers, start the workers and begin filling batches now (idempotent).  The workers need ~0.5 s to come up
-        (spawn + imports): a caller that starts the loader before it builds its GPU context hides that behind the set-up."""
-        if self._thread is not None:
-            return self
-        self._open()
-        self._q = queue.Queue(maxsize=self.prefetch)
-        self._stop_evt = threading.Event()
-        q, stop, FILL = self._q, self._stop_evt, self.fill
-
-        def producer():
-            turn = 0
-            try:
-                starts = iter(range(self.lo, self.hi, self.B))
-                pending = collections.deque()
-                while True:
-                    while len(pending) < FILL:
-                        s = next(starts, None)
-                        if s is None:
-                            break
-                        e = min(s + self.B, self.hi)
-                        ridx = turn % self.nring
-                        turn += 1
-                        futs = [self._pool.submit(_proc_fill, ridx, w - s, w, min(self.chunk, e - w)) for w in range(s, e, self.chunk)]
-                        pending.append((s, e, ridx, futs))
-                    if not pending or stop.is_set():
-                        break
-                    s, e, ridx, futs = pending.popleft()
-                    for f in futs:
-                        f.result()
-                    q.put((s, e, tuple(v[:e - s] for v in self._views[ridx]), None))
-                for _, _, _, futs in pending:
-                    for f in futs:
-                        f.cancel()
-            except BaseException as exc:            # noqa: BLE001 — hand the failure to the consumer
-                q.put((None, None, None, exc))
-                return
-            q.put(None)
-
-        self._thread = threading.Thread(target=producer, daemon=True)
-        self._thread.start()
+        """Create the buffers, start the workers and begin filling batches now (idempotent): the first ``nring`` batches are
+        decoded while the caller is still setting up its GPU context."""
+        if not self._started:
+            self._open()
+            self._started = True
         return self
+
+    def _wait_for(self, bi):
+        """block until every chunk of batch bi is in its buffer; re-raises a worker's failure"""
+        P, total = self.procs, len(self) * self._cpb
+        upto = min((bi + 1) * self._cpb, total)
+        for c in range(self._need_upto, upto):
+            self._need[_chunk_owner(c, self._cpb * self.nring, P)] += 1
+        self._need_upto = max(self._need_upto, upto)
+        prog = self._ctrl[2:2 + P]
+        while not (prog >= self._need).all():
+            if not self._sem.acquire(timeout=0.05):
+                for p in self._pool:
+                    if not p.is_alive() and p.exitcode not in (0, None):
+                        raise RuntimeError("a loader worker died (exit code %s)" % p.exitcode)
+            if self._ctrl[1]:
+                if not self._errq.empty():
+                    raise self._errq.get()
+                raise RuntimeError("the loader's workers stopped")
 
     def __iter__(self):
         self.start()
-        q, stop, t = self._q, self._stop_evt, self._thread
+        nb = len(self)
         try:
-            while True:
-                item = q.get()
-                if item is None:
-                    return
-                s, e, batch, exc = item
-                if exc is not None:
-                    raise exc
-                yield s, e, batch
+            for bi in range(nb):
+                # asking for batch bi releases the batches up to bi - 1 - hold: their ring entries may be refilled
+                self._ctrl[0] = max(0, bi - self.hold) + self.nring
+                self._wait_for(bi)
+                s = self.lo + bi * self.B
+                e = min(s + self.B, self.hi)
+                yield s, e, tuple(v[:e - s] for v in self._views[bi % self.nring])
         finally:
-            stop.set()
-            while t.is_alive():
-                try:
-                    q.get_nowait()
-                except queue.Empty:
-                    pass
-                t.join(timeout=0.05)
-            self._thread = None
+            self._started = False
             self._stop()
 
 

@@ -21,11 +21,26 @@ import os
 import sys
 import time
 
-import numpy as np
+_T_IMPORT = time.time()          # before numpy and the package: the first mark of the start-up split (--report)
 
-from . import sequence as S
-from .davo import DAVO
-from .version import FLAGSHIP_VERSION
+import numpy as np               # noqa: E402
+
+from . import sequence as S              # noqa: E402
+from .davo import DAVO                   # noqa: E402
+from .version import FLAGSHIP_VERSION    # noqa: E402
+
+
+_FIRST_MAIN = True
+
+
+def _process_start_time():
+    """wall-clock time this process was created (the kernel's record: /proc/self/stat field 22 against the boot time)"""
+    try:
+        ticks = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[19])
+        btime = next(int(ln.split()[1]) for ln in open("/proc/stat") if ln.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, StopIteration):
+        return None
 
 
 def main(argv=None):
@@ -55,9 +70,19 @@ def main(argv=None):
     ap.add_argument("--emulate_shard", default=None, metavar="r/R",
                     help="measurement aid: do what rank r of R would do (its window shard, the gather, the whole stitch) in this one process")
     ap.add_argument("--report", default=None, help="write the run's time split (load wait / forward / gather / stitch / write) as JSON here")
+    ap.add_argument("--sync_driver", action="store_true",
+                    help="one synchronous davo_forward per batch (input wait + copy + kernels + pose copy add up) instead of the streaming "
+                         "entry point (davo_submit: three batches in flight, copies and input wait overlapped with the kernels)")
     a = ap.parse_args(argv)
+    # start-up split (wall clock).  Only the first main() of a process can say what the process start cost
+    global _FIRST_MAIN
+    fresh, _FIRST_MAIN = _FIRST_MAIN, False
+    marks = [("interpreter_up", _T_IMPORT), ("imports_done", time.time())] if fresh else [("main_entered", time.time())]
 
-    from .comm import RcclComm, world_from_env
+    def mark(name):
+        marks.append((name, time.time()))
+
+    from .comm import RcclComm, world_from_env, preload_in_background
     rank, local_rank, world = world_from_env()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the parent only starts the ranks and waits; it never touches a GPU
@@ -67,11 +92,16 @@ def main(argv=None):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     device_index = local_rank
     emulate = tuple(int(x) for x in a.emulate_shard.split("/")) if a.emulate_shard else None
-    if not a.synthetic and a.loader_procs != 0:
-        # first thing this rank does: the fork server the loader's workers come from starts importing numpy / Pillow now, behind
-        # this process's own imports, the checkpoint read and the GPU set-up (davo_amd/loader.py: worker_context)
-        from .loader import warm_workers
-        warm_workers()
+    need_comm = world > 1 or a.force_comm
+    # Start-up is a rank's whole run on a sharded sequence (a 568-window shard is 0.1 s of work), so everything that does not depend
+    # on each other starts at once: librccl loads on a thread of its own (573 MB to map: most of a second, needed only at the
+    # gather), the input pipeline's workers fork and its buffers are created and page-locked on another, while this thread reads
+    # the checkpoint and builds the GPU context.  (Round 4 did these one after the other: 2.9 s from process start to the first
+    # batch in a fresh process, 1.7 s of it the communicator: profiles/r05b_config4_scene_streamed.json.)
+    if need_comm:
+        preload_in_background()
+    import threading
+    loader_thread = None
 
     H, W = a.img_height, a.img_width
     if a.synthetic:
@@ -80,9 +110,12 @@ def main(argv=None):
         load = S.synthetic_window_loader(H, W)
         weights = synth.make_weights(a.version)
     else:
-        from glob import glob
+        if a.loader_procs != 0:
+            # the fork server the loader's workers come from starts importing numpy / Pillow now (davo_amd/loader.py: worker_context)
+            from .loader import warm_workers
+            warm_workers()
         d = os.path.join(a.concat_img_dir, "%.2d" % a.test_seq)
-        n_frames = len(glob(d + "/*.jpg")) + 2 * int((a.seq_length - 1) / 2)      # test_kitti_pose.py:81-82
+        n_frames = sum(1 for f in os.listdir(d) if f.endswith(".jpg")) + 2 * int((a.seq_length - 1) / 2)      # test_kitti_pose.py:81-82
         from .davo import pinned_empty, pin_array, unpin_array    # batches are decoded straight into page-locked memory
         procs = a.loader_procs
         if procs < 0:
@@ -100,28 +133,47 @@ def main(argv=None):
                                      alloc=lambda shape, dtype: pinned_empty(shape, dtype, device_index),
                                      workers=a.loader_threads, decode_procs=a.decode_procs, procs=procs,
                                      pin=lambda arr: pin_array(arr, device_index), unpin=unpin_array,
-                                     seg_planes=(0, 1, 2) if static_all else None)
-        # the loader's workers come up (spawn + imports: ~0.5 s) while the checkpoint is read and the GPU context is built
-        load.prestart(*S.shard_windows(n_frames - 2, *((world, rank) if emulate is None else (emulate[1], emulate[0]))), a.batch_size)
+                                     seg_planes=(0, 1, 2) if static_all else None, hold=0 if a.sync_driver else 1)
+        # the loader's buffers are created and page-locked (1.4 GB at batch 64: 0.2-0.3 s) and its workers start filling them on a
+        # thread of its own while the checkpoint is read and the GPU context is built
+        shard = S.shard_windows(n_frames - 2, *((world, rank) if emulate is None else (emulate[1], emulate[0])))
+        loader_thread = threading.Thread(target=load.prestart, args=(shard[0], shard[1], a.batch_size), name="davo-loader-start")
+        loader_thread.start()
         from .tf_checkpoint import load_weights
         weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
+    mark("inputs_and_weights_ready")
 
     system = DAVO(version=a.version, device=device_index)
     system.load_weights(weights)
+    from . import _lib
+    _lib.lib()
+    mark("library_loaded")
     system.setup_inference(H, W, "davo", a.seq_length, a.batch_size)
+    mark("context_and_weights_on_gpu")
+    # the communicator is not needed before the gather: the id exchange and ncclCommInitRank run on a second thread from here on
+    # (collective; fails loudly at the gather, no other transport)
+    comm = RcclComm.from_env_async(system.engine) if need_comm else None
     infer = lambda img, flow, seg: system.inference(None, "pose", inputs=(img, flow, seg))["pose"]   # noqa: E731
     if not a.no_calibrate:
-        # every rank calibrates on the same first windows, so the trajectory does not depend on the world size
-        system.calibrate(load(0, min(a.batch_size, n_frames - 2)))
-
-    comm = RcclComm.from_env(system.engine) if (world > 1 or a.force_comm) else None      # collective; fails loudly, no other transport
+        # every rank calibrates on the same first windows, so the trajectory does not depend on the world size.  Eight windows at
+        # most: the scales are powers of two with 64x headroom, and loading them inline is in front of the first batch
+        system.calibrate(load(0, min(a.batch_size, 8, n_frames - 2)))
+    mark("calibrated_first_forward_done")
+    if loader_thread is not None:
+        loader_thread.join()
+    mark("loader_started")
+    # streamed: a batch of the process loader stays valid while the next one is asked for (hold = 1), so davo_submit does not wait for
+    # its own copy; the threaded loader and the synthetic windows give no such promise (hold = 0)
+    from .loader import ProcessWindowLoader
+    stream_hold = lambda ld: 1 if isinstance(ld, ProcessWindowLoader) else 0      # noqa: E731
     t0 = time.perf_counter()
     timing = {}
     # this rank's prefetching loader (started above): handed in ready-made and closed only after the trajectory is written -
     # unpinning and unmapping ~1 GB of batch buffers takes 0.15 s and used to run inside run_sequence when the last reference died
     lo_hi = S.shard_windows(n_frames - 2, *((world, rank) if emulate is None else (emulate[1], emulate[0])))
     ld = load.for_range(*lo_hi, a.batch_size) if hasattr(load, "for_range") else load
-    traj, poses = S.run_sequence(infer, ld, n_frames, a.batch_size, rank, world, comm, timing, emulate)
+    stream = None if a.sync_driver else S.PoseStream(system.engine, hold=stream_hold(ld))
+    traj, poses = S.run_sequence(infer, ld, n_frames, a.batch_size, rank, world, comm, timing, emulate, stream)
     dt = time.perf_counter() - t0
     if rank == 0:
         os.makedirs(a.output_dir, exist_ok=True)
@@ -129,13 +181,28 @@ def main(argv=None):
         tw = time.perf_counter()
         S.write_kitti_poses(out, traj)
         timing["write_s"] = time.perf_counter() - tw
+        t_proc = _process_start_time()
+        names = [m[0] for m in marks]
+        times = [m[1] for m in marks]
+        startup = {"%s_s" % names[i]: times[i] - times[i - 1] for i in range(1, len(marks))}
+        if t_proc is not None and fresh:
+            startup["process_start_to_interpreter_up_s"] = times[0] - t_proc
+            startup["process_start_to_first_batch_s"] = times[-1] - t_proc
+        startup["first_batch_to_trajectory_written_s"] = time.time() - times[-1]
+        if getattr(comm, "t_ready", None) is not None and t_proc is not None and fresh:
+            startup["process_start_to_communicator_ready_s"] = comm.t_ready - t_proc      # built on a second thread; the gather waited for it
+            startup["process_start_to_trajectory_written_s"] = time.time() - t_proc
+        timing["startup"] = {k: round(v, 4) for k, v in startup.items()}
         timing.update(total_s=dt + timing["write_s"], windows=n_frames - 2, world=world, batch_size=a.batch_size,
                       windows_per_s=(n_frames - 2) / dt, range_recovery=system.engine.range_stats(),
                       note="rank 0's seconds; load_wait_s = time the GPU side waited for the input pipeline, forward_s = H2D + kernels + "
-                           "pose D2H inside DAVO.inference, gather_s = the RCCL all-gather incl. staging")
+                           "pose D2H inside DAVO.inference (streamed: the time inside davo_submit), gather_s = the RCCL all-gather incl. staging and the "
+                           "wait for the communicator, which is built on a second thread from the moment the GPU context exists")
         print("Done. Please check %s  (%d windows on %d GPU(s) in %.2f s incl. input generation/IO: input wait %.2f, forward %.2f, "
-              "gather %.3f, stitch %.2f, write %.2f)" % (out, n_frames - 2, world, dt, timing["load_wait_s"], timing["forward_s"],
-                                                         timing["gather_s"], timing["stitch_s"], timing["write_s"]))
+              "gather %.3f, stitch %.2f, write %.2f%s)" % (out, n_frames - 2, world, dt, timing["load_wait_s"], timing["forward_s"],
+                                                           timing["gather_s"], timing["stitch_s"], timing["write_s"],
+                                                           "; streamed: forward = time inside davo_submit, drain %.3f" % timing["drain_s"]
+                                                           if "drain_s" in timing else ""))
         if a.report:
             import json
             with open(a.report, "w") as f:

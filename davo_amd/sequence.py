@@ -126,17 +126,42 @@ def _pad_batch(img, flow, seg, batch_size):
     return img, flow, seg, n
 
 
-def run_shard(infer_fn, load_windows, lo, hi, batch_size, timing=None):
+class PoseStream:
+    """The library's streaming entry point (include/davo_hip.h: davo_submit / davo_wait) as run_shard's ``stream``: batches
+    are issued without waiting for their poses, so the H2D copy and the kernels of batch n+1 run while batch n computes and
+    while the loader is asked for batch n+2 - what tf.data's prefetch does for the reference's loop
+    (test_kitti_pose.py:133-145, data_loader.py:321-324).  ``hold``: batches whose input arrays the source keeps valid after
+    yielding the next one (0 for davo_amd.loader's loaders; arrays that are never recycled can take 8: no copy is waited for).
+    ``inflight``: slots = streams the batches rotate through; a slot's stream runs copy -> kernels -> pose copy in order, so at
+    batch 1 (44 us of copy latency in front of 127 us of kernels) three slots keep the GPU busier than two: 8.7 k -> 10.5 k
+    windows/s on 799 windows (profiles/r05b_config1_b1.json)."""
+
+    def __init__(self, engine, inflight=3, hold=0):
+        self.engine, self.hold = engine, hold
+        engine.set_inflight(inflight)
+
+    def submit(self, img, flow, seg, out):
+        self.engine.submit(img, flow, seg, out, self.hold)
+
+    def drain(self):
+        self.engine.synchronize()
+
+
+def run_shard(infer_fn, load_windows, lo, hi, batch_size, timing=None, stream=None):
     """Run windows [lo,hi) in batches; the last batch is padded by repeating its last window
     and the padded outputs are dropped (the reference's complete_batch_size,
     utils/common_utils.py:8-13, would append duplicate poses for B>1; parity is defined on
     B=1 semantics).
+
+    ``stream`` (a PoseStream) replaces ``infer_fn``: batches are submitted and their poses collected at the end, so input
+    wait, copies and kernels overlap instead of adding up; the poses are the same bits (same kernels on the same batches).
 
     ``load_windows`` is either a callable ``(s, e) -> (img, flow, seg)`` or an iterable of
     ``(s, e, (img, flow, seg))`` in window order (davo_amd.loader.ThreadedWindowLoader: the next
     batches are decoded while this one is on the GPU).  ``timing`` (a dict) receives the seconds spent waiting for
     input and inside ``infer_fn``."""
     out = np.zeros((hi - lo, 2, 6), np.float32)
+    tails = []                                            # streamed partial batches: (padded poses, where they go)
     if callable(load_windows):
         batches = ((s, min(s + batch_size, hi), load_windows(s, min(s + batch_size, hi))) for s in range(lo, hi, batch_size))
     else:
@@ -151,11 +176,29 @@ def run_shard(infer_fn, load_windows, lo, hi, batch_size, timing=None):
             break
         s, e, (img, flow, seg) = item
         img, flow, seg, n = _pad_batch(img, flow, seg, batch_size)
-        out[s - lo:e - lo] = np.asarray(infer_fn(img, flow, seg))[:n]
+        if stream is None:
+            out[s - lo:e - lo] = np.asarray(infer_fn(img, flow, seg))[:n]
+        elif n == batch_size:
+            stream.submit(img, flow, seg, out[s - lo:e - lo])          # delivered straight into its rows of `out`
+        else:
+            full = np.empty((batch_size, 2, 6), np.float32)
+            stream.submit(img, flow, seg, full)
+            tails.append((full, s - lo, n, (img, flow, seg)))           # the padded copies stay alive until the drain
         t_fwd += time.perf_counter() - t1
+    if stream is not None:
+        t1 = time.perf_counter()
+        stream.drain()
+        for full, at, n, _ in tails:
+            out[at:at + n] = full[:n]
+        t_drain = time.perf_counter() - t1
     if timing is not None:
         timing["load_wait_s"] = timing.get("load_wait_s", 0.0) + t_load
-        timing["forward_s"] = timing.get("forward_s", 0.0) + t_fwd       # H2D copies + kernels + D2H of the poses (davo_forward)
+        # synchronous driver: H2D copies + kernels + D2H of the poses (davo_forward).  Streamed: the time inside davo_submit - issuing
+        # the batch and waiting for ITS H2D copy, while the previous batches compute - and drain_s, the wait for the last batches
+        timing["forward_s"] = timing.get("forward_s", 0.0) + t_fwd
+        if stream is not None:
+            timing["drain_s"] = timing.get("drain_s", 0.0) + t_drain
+            timing["streamed"] = True
     return out
 
 
@@ -179,19 +222,19 @@ def gather_poses(local, n_windows, world, rank, comm=None):
     return np.concatenate(parts, 0)
 
 
-def run_sequence(infer_fn, load_windows, n_frames, batch_size, rank=0, world=1, comm=None, timing=None, emulate=None):
+def run_sequence(infer_fn, load_windows, n_frames, batch_size, rank=0, world=1, comm=None, timing=None, emulate=None, stream=None):
     """The driver loop of test_kitti_pose.py:133-149, sharded: returns the Nf 4x4 poses on
     every rank (the stitch is cheap and sequential; rank 0 writes the file).  ``timing`` (a dict) receives this
     rank's seconds per stage: load_wait_s, forward_s, gather_s, stitch_s.
 
     ``emulate=(r, R)`` (measurement aid, one process): do exactly what rank r of R would do - its window shard, the gather
     (through ``comm`` at its real world size, normally 1), the stitch of the whole sequence - with the other ranks' windows left
-    at zero motion."""
+    at zero motion.  ``stream`` (a PoseStream): the shard runs through the library's streaming entry point (run_shard)."""
     n_windows = n_frames - 2
     lo, hi = shard_windows(n_windows, *((world, rank) if emulate is None else (emulate[1], emulate[0])))
     if hasattr(load_windows, "for_range"):               # a loader factory: build this rank's prefetching loader
         load_windows = load_windows.for_range(lo, hi, batch_size)
-    local = run_shard(infer_fn, load_windows, lo, hi, batch_size, timing)
+    local = run_shard(infer_fn, load_windows, lo, hi, batch_size, timing, stream)
     t0 = time.perf_counter()
     if emulate is None:
         poses = gather_poses(local, n_windows, world, rank, comm)
@@ -211,10 +254,11 @@ class kitti_window_loader:
     threaded, prefetching batch iterator of a rank's shard; calling it ``(s, e)`` loads one batch inline."""
 
     def __init__(self, concat_img_dir, seq, n_frames, H, W, workers=4, prefetch=2, alloc=None, decode_procs=0, procs=0,
-                 pin=None, unpin=None, seg_planes=None):
+                 pin=None, unpin=None, seg_planes=None, hold=0):
         self.dir, self.seq, self.n_frames, self.H, self.W = concat_img_dir, seq, n_frames, H, W
         self.workers, self.prefetch, self.alloc, self.decode_procs = workers, prefetch, alloc, decode_procs
         self.procs, self.pin, self.unpin, self.seg_planes = procs, pin, unpin, seg_planes
+        self.hold = hold          # batches the process loader keeps valid beyond the one being asked for (PoseStream(hold=...)); the threaded loader gives 0
 
     def prestart(self, lo, hi, batch_size):
         """Build this rank's process loader now and let it start filling batches: the workers fork, attach the buffers and
@@ -233,7 +277,7 @@ class kitti_window_loader:
         if self.procs > 0:      # worker processes fill shared (page-locked) batch buffers: davo_amd/loader.py, ProcessWindowLoader
             try:
                 return L.ProcessWindowLoader(self.dir, self.seq, self.H, self.W, lo, hi, batch_size, self.procs, self.prefetch,
-                                             pin=self.pin, unpin=self.unpin,
+                                             pin=self.pin, unpin=self.unpin, hold=self.hold,
                                              seg_planes=L.SEG_PLANES_SOURCES if self.seg_planes is None else self.seg_planes)
             except L.ShmBudgetError as e:      # e.g. a container with the usual 64 MB /dev/shm: decode threads into pinned buffers instead
                 import sys

@@ -79,12 +79,18 @@ int davo_forward(davo_ctx* ctx, int B, const uint8_t* img, const float* flow, co
  * which case it is bracketed by HIP events, synchronised, and the device time is returned.
  * With davo_set_inflight(ctx, n > 1) the timed form still waits for its own batch only and the
  * batches of all slots are judged together at davo_synchronize().
- * f16x3 range guard: the asynchronous form cannot know its own result, so every batch gets a range record of its own
- * and is judged later: when its slot of a ring of 8 is needed again (eight batches on), at davo_synchronize(), or before
+ * f16x3 range guard: the asynchronous form cannot know its own result, so every batch gets a slot of a ring of range
+ * records (running maxima: "clamped" is exact per batch, "too small" covers what the slot has stored since its record was last
+ * zeroed - at a failed verdict, a change of scales, and for every 256th batch) and is judged later: when its slot of a ring of 8 is needed again (eight batches on), at davo_synchronize(), or before
  * anything that changes the storage scales.  A failed verdict RE-ISSUES that batch (see "auto_range" below) and
  * rewrites its pose buffer, so:
  *   - the OUTPUT buffer of a batch must stay alive until davo_synchronize() has returned, and its poses are final only
- *     then (davo_range_stats / davo_range_report say whether anything was re-issued);
+ *     then (davo_range_stats / davo_range_report say whether anything was re-issued).  A pose buffer may be handed to a
+ *     later batch before that (two alternating buffers; one buffer overwritten every step): the newest batch issued into a
+ *     range of memory always wins - a re-issue writes into a buffer of the context first and is copied to the batch's own
+ *     pose buffer only if no batch issued after it targets an overlapping range.  What such a caller cannot have is FINAL
+ *     poses per batch before it synchronises (a D2H copy ordered on the stream behind batch n reads batch n's first issue):
+ *     streaming callers use davo_submit / davo_wait below, where the library owns the pose buffers and delivers final poses;
  *   - the INPUT buffers (16-byte aligned) may be overwritten or recycled as soon as work ordered behind the call on
  *     the context's stream may run (e.g. the next H2D on that stream, or anything behind an event recorded there):
  *     the batch's last kernel sees the finished range record and, if the batch will have to be re-issued, copies
@@ -95,6 +101,28 @@ int davo_forward(davo_ctx* ctx, int B, const uint8_t* img, const float* flow, co
  * The timed, synchronous form judges (and re-issues) its own batch; elapsed_ms is then the first issue's time. */
 int davo_forward_device(davo_ctx* ctx, int B, const void* d_img, const void* d_flow,
                         const void* d_seg, void* d_pose, float* elapsed_ms);
+
+/* The sequence loop as a stream.  The reference's driver pulls batches through tf.data's prefetch(8*B) while the session runs
+ * (test_kitti_pose.py:133-145, data_loader.py:321-324), so input transfer, compute and result delivery of neighbouring batches
+ * overlap; davo_forward returns poses and cannot.  davo_submit takes host pointers shaped as davo_forward's and rotates through the
+ * in-flight slots (davo_set_inflight) like davo_forward_device: on the slot's own stream it queues the H2D copies of the planes the
+ * path reads into the slot's staging set, the forward, and the D2H of the poses into a page-locked ring entry of the context.  With
+ * two or more slots the copies of batch n+1 run under the kernels of batch n (one slot: copy and kernels alternate, still without
+ * the host waiting for either).  It returns once the input buffers of the batch submitted `hold` calls earlier have been copied:
+ * hold = 0 - on return THIS batch's img / flow / seg may be overwritten (a loader that recycles a batch when the next one is
+ * asked for); hold = k - the caller keeps a batch's inputs unchanged for k more submits and the call waits for a copy that is
+ * probably done already (k >= 8 never waits for a copy and records no event).  Page-locked inputs (davo_host_alloc /
+ * davo_host_register) copy as DMA; pageable ones work, synchronously.
+ * pose_out [B,2,6] is written BY THE HOST when the batch is delivered: after its f16x3 range ticket has been judged and, if it
+ * failed, the batch re-issued (re-calibrated / float32 kernels, from the context's own copy of its inputs into the context's own
+ * pose buffer).  Delivery happens in submission order inside later davo_submit calls (whatever has finished by then; the oldest
+ * is waited for once eight batches are undelivered), davo_wait and davo_synchronize.  pose_out must stay valid until then; it may
+ * be pageable.  davo_wait(ctx, n) returns once at most n submitted batches are undelivered (n = 0: all delivered; the streams may
+ * still be busy with range bookkeeping, davo_synchronize also idles them).  davo_pending = undelivered batches (>= 0).
+ * davo_forward, davo_set_stream and davo_set_inflight deliver everything first. */
+int davo_submit(davo_ctx* ctx, int B, const uint8_t* img, const float* flow, const float* seg, float* pose_out, int hold);
+int davo_wait(davo_ctx* ctx, int leave_pending);
+int davo_pending(davo_ctx* ctx);
 
 const char* davo_last_error(const davo_ctx* ctx);
 void davo_destroy(davo_ctx* ctx);
@@ -120,7 +148,8 @@ int davo_memcpy_d2h(davo_ctx* ctx, void* dst, const void* src, size_t bytes);
  * holds float32-grade results.  With "auto_range" 0 the first failed verdict is returned as DAVO_ERR_RANGE instead
  * (the poses of that batch are not float32-grade; all batches have been judged, nothing stays pending). */
 int davo_synchronize(davo_ctx* ctx);
-/* Run on a caller-owned hipStream_t (NULL restores the context's own stream). */
+/* Run on a caller-owned hipStream_t (NULL restores the context's own stream).  Batches issued on the stream the context leaves
+ * are judged (and, if need be, re-issued) inside this call, i.e. it waits for them: the old stream may be destroyed afterwards. */
 int davo_set_stream(davo_ctx* ctx, void* hip_stream);
 /* Number of batches davo_forward_device keeps in flight (1..4, default 1).  With n > 1 the context
  * owns n streams and n activation workspaces and successive calls rotate through them, so the small
@@ -265,8 +294,14 @@ int davo_set_option(davo_ctx* ctx, const char* key, int value);
  *     out), after the context's own streams have drained.
  *   davo_comm_allreduce: one double, in place; op 0 sum | 1 max | 2 min (bench.py: max-over-ranks).
  *   davo_comm_barrier: every stream of this context idle, then a rendezvous of all ranks.
+ *   davo_comm_preload: only loads librccl (573 MB to map, its code objects to register: most of a second); needs no context and
+ *     may run on any thread, e.g. at process start behind the host's own imports.
+ * Threads: davo_comm_preload, davo_comm_unique_id and davo_comm_init may run on a second host thread while the context's owner
+ * thread issues forwards (a communicator takes seconds to build and is not needed before the gather); davo_comm_init publishes
+ * the communicator into the context as its last step.  Every other call of this group belongs to the owner thread.
  * Errors: DAVO_ERR_COMM (message names the RCCL call); there is no fallback transport. */
 #define DAVO_COMM_ID_BYTES 128
+int davo_comm_preload(char* err, int err_len);
 int davo_comm_unique_id(void* id_out, char* err, int err_len);
 int davo_comm_init(davo_ctx* ctx, int nranks, int rank, const void* id);
 int davo_comm_size(davo_ctx* ctx, int* nranks, int* rank);

@@ -135,6 +135,29 @@ def test_process_loader_fills_shared_buffers_with_the_planes_the_path_reads(dump
     assert (s, e) == (2, 7) and all(np.array_equal(flow[i], ref[2 + i][1]) and np.array_equal(seg[i], ref[2 + i][2]) for i in range(5))
 
 
+def test_process_loader_hold_keeps_earlier_batches_valid(dump):
+    """hold = k: a batch stays valid until k + 1 further ones have been asked for (the streaming driver submits batch n while its
+    copy of batch n - 1 may still be running); the ring is k entries longer for the same number of batches in flight."""
+    d, n_windows, H, W = dump, 7, 32, 64
+    ref = {w: L.load_window(d, 3, w + 1, H, W) for w in range(n_windows)}
+    plain = L.ProcessWindowLoader(d, 3, H, W, 0, n_windows, 1, procs=2, prefetch=1)
+    ld = L.ProcessWindowLoader(d, 3, H, W, 0, n_windows, 1, procs=2, prefetch=1, hold=2)
+    assert ld.nring == plain.nring + 2
+    plain.close()
+    import time
+    kept = []
+    for s, e, (img, flow, seg) in ld:
+        kept.append((s, img, flow, seg))
+        time.sleep(0.05)                                                     # the workers run ahead as far as the ring allows
+        for s0, i0, f0, g0 in kept[-3:]:                                     # this batch and the two before it are intact
+            assert np.array_equal(i0[0], ref[s0][0]) and np.array_equal(f0[0, :2], ref[s0][1][:2]) and np.array_equal(g0[0, 0], ref[s0][2][0])
+    assert [k[0] for k in kept] == list(range(n_windows))
+    ld.close()
+    with pytest.raises(L.ShmBudgetError):
+        per = H * 3 * W * 3 + 4 * H * W * 2 * 4 + 3 * H * W * 4
+        L.ProcessWindowLoader(d, 3, H, W, 0, n_windows, 1, procs=2, hold=2, shm_budget=5 * per)      # 4 + hold entries are the minimum
+
+
 def test_process_loader_propagates_a_missing_file(dump, tmp_path):
     import shutil
     d, n_windows, H, W = dump, 7, 32, 64

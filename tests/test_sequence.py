@@ -3,6 +3,7 @@
 tests/golden/kitti_gt_poses_03.txt is a DATA fixture: the KITTI ground-truth poses of sequence 03
 that the reference ships under kitti_benchmark/data/odometry/poses/03.txt (801 lines x 12 floats)."""
 import os
+import sys
 import time
 
 import numpy as np
@@ -89,6 +90,40 @@ def test_run_shard_pads_and_drops():
     assert np.array_equal(out[:, 0, 0], np.arange(3, 10))    # and the padded outputs are dropped
 
 
+def test_run_shard_streamed_submits_in_order_and_collects_at_the_drain():
+    """run_shard(stream=...): full batches are delivered straight into their rows, the ragged last batch is padded, kept alive
+    until the drain and its padded rows dropped - with a stand-in that delivers LATE (at drain), like the library's entry point."""
+    class LateStream:
+        def __init__(self):
+            self.jobs, self.drained = [], 0
+
+        def submit(self, img, flow, seg, out):
+            assert out.flags.c_contiguous and out.dtype == np.float32 and out.shape == (img.shape[0], 2, 6)
+            self.jobs.append((img[:, 0, 0, 0].astype(np.float32).copy(), out))       # hold = 0: the inputs are consumed on return
+
+        def drain(self):
+            self.drained += 1
+            for ids, out in self.jobs:
+                out[...] = ids[:, None, None]
+
+    def load(s, e):
+        n = e - s
+        img = np.zeros((n, 4, 12, 3), np.uint8)
+        img[:, 0, 0, 0] = np.arange(s, e)
+        return img, np.zeros((n, 4, 4, 4, 2), np.float32), np.zeros((n, 3, 4, 4, 1), np.float32)
+    st = LateStream()
+    timing = {}
+    out = S.run_shard(None, load, 3, 13, 4, timing, st)
+    assert [j[0].shape[0] for j in st.jobs] == [4, 4, 4] and st.drained == 1
+    assert np.array_equal(out[:, 1, 5], np.arange(3, 13))
+    assert timing["streamed"] and {"load_wait_s", "forward_s", "drain_s"} <= set(timing)
+    # same through run_sequence, iterable loaders included
+    batches = [(s, min(s + 4, 10), load(s, min(s + 4, 10))) for s in range(0, 10, 4)]
+    st2 = LateStream()
+    traj, poses = S.run_sequence(None, batches, 12, 4, stream=st2)
+    assert np.array_equal(poses[:, 0, 0], np.arange(10)) and len(traj) == 12
+
+
 class GlooComm:
     """Test stand-in with RcclComm's allgather contract (davo_amd/comm.py) over gloo on CPU: the product gathers
     through librccl (davo_allgather_poses), which needs one GPU per rank; the sharding logic around it does not."""
@@ -167,6 +202,9 @@ def test_gather_needs_a_communicator_and_orders_ragged_shards():
 
 _CHILD = """
 import os, sys
+sys.path.insert(0, '@ROOT@')
+from davo_amd.launch import bind_rank_cpus          # what `import davo_amd` and bench.py do first: the rank binds itself
+bind_rank_cpus()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.path.isdir(os.environ["DAVO_COMM_DIR"])
 assert len(os.environ["DAVO_COMM_NONCE"]) == 16 and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
@@ -174,7 +212,7 @@ cpus = ",".join(str(c) for c in sorted(os.sched_getaffinity(0)))
 open(os.path.join(sys.argv[1], "rank%d" % rank), "w").write(os.environ["DAVO_COMM_DIR"])
 open(os.path.join(sys.argv[1], "cpus%d" % rank), "w").write(cpus)
 sys.exit(int(sys.argv[2]) if rank == int(sys.argv[3]) else 0)
-"""
+""".replace("@ROOT@", os.path.dirname(HERE))
 
 
 def test_spawn_ranks_sets_the_launch_contract_and_fails_if_any_rank_fails(tmp_path):
@@ -194,6 +232,25 @@ def test_spawn_ranks_sets_the_launch_contract_and_fails_if_any_rank_fails(tmp_pa
     assert cpu_slices(4, cpus=range(10)) == [{0, 1}, {2, 3, 4}, {5, 6}, {7, 8, 9}]
     assert cpu_slices(3, cpus=[5, 9]) == [{5, 9}] * 3                   # fewer CPUs than ranks: nobody is pinned
     assert spawn_ranks([str(script), str(tmp_path), "7", "1"], 3) == 7  # rank 1 exits 7 -> the run is a failure
+
+
+def test_no_process_of_the_package_replaces_its_own_program():
+    """An exec from a process that a preloaded library has made a GPU process (rocprofv3 -- python bench.py --gpus N) takes the
+    machine down on this pool: ranks bind their CPUs themselves (DAVO_CPU_SLICE), nothing under davo_amd/ or bench.py execs."""
+    import re
+    root = os.path.dirname(HERE)
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    files += [os.path.join(root, "davo_amd", f) for f in os.listdir(os.path.join(root, "davo_amd")) if f.endswith(".py")]
+    for f in files:
+        code = "\n".join(l.split("#", 1)[0] for l in open(f).read().splitlines())
+        code = re.sub(r'"""(?:.|\n)*?"""', "", code)
+        assert not re.search(r"\bos\.(exec[a-z]*|spawn[a-z]*|posix_spawn[a-z]*)\s*\(|\bexecv[pe]*\s*\(", code), f
+    # and `import davo_amd` itself binds a rank that finds DAVO_CPU_SLICE, before numpy is imported
+    import subprocess
+    one = sorted(os.sched_getaffinity(0))[-1]
+    out = subprocess.check_output([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import davo_amd, os; "
+                                   "print(sorted(os.sched_getaffinity(0)))" % root], env=dict(os.environ, DAVO_CPU_SLICE=str(one)), text=True)
+    assert out.strip() == str([one])
 
 
 def test_bench_and_cli_parents_do_not_load_the_hip_library():

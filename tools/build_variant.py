@@ -19,4 +19,5 @@ if __name__ == "__main__":
         raise SystemExit(__doc__)
     from davo_amd import _lib
     print(_lib.build(force="--force" in sys.argv, verbose=True, suffix=sys.argv[1],
-                     extra_flags=[a for a in sys.argv[2:] if a != "--force"]))
+                     extra_flags=[a for a in sys.argv[2:] if a not in ("--force", "--allow-packed-f32")],
+                     allow_packed_f32="--allow-packed-f32" in sys.argv))      # e.g. the reproducers of DESIGN.md section 4 (fa, e5...)

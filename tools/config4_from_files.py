@@ -3,7 +3,10 @@
 reference's on-disk format -> CLI (worker-process loader, RCCL all-gather forced at world size 1) -> trajectory, with the run's
 time split.  The dump holds 640 distinct windows; the rest are links to them (same files, same decode work, warm page cache).
 
-    python tools/config4_from_files.py [out.json] [--shard r/R] [--images noise|scene]      # --shard 3/8: only what rank 3 of 8 would do (568 windows)"""
+    python tools/config4_from_files.py [out.json] [--shard r/R] [--images noise|scene] [--sync] [--fresh]
+        --shard 3/8: only what rank 3 of 8 would do (568 windows); --sync: the synchronous driver (one davo_forward per batch)
+        instead of the streaming entry point; --fresh: every run is a process of its own (`python -m davo_amd.run_kitti_pose`),
+        so the report's start-up split (process start -> first batch) is a rank's real one"""
 import json
 import os
 import sys
@@ -28,6 +31,9 @@ def main():
     images = argv.pop(argv.index("--images") + 1) if "--images" in argv else "noise"
     if "--images" in argv:
         argv.remove("--images")
+    sync = "--sync" in argv
+    fresh = "--fresh" in argv
+    argv = [a for a in argv if a not in ("--sync", "--fresh")]
     out = argv[0] if argv else None
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         L.write_synthetic_dump(d, 0, real, H, W, images=images)
@@ -39,16 +45,22 @@ def main():
         runs = []
         for rep in range(3):                                           # run 0 pays the library's first load and the cold page cache
             t0 = time.perf_counter()
-            run_kitti_pose.main(["--concat_img_dir", d, "--ckpt_file", os.path.join(d, "w.npz"), "--output_dir", d, "--test_seq", "0",
-                                 "--batch_size", str(B), "--force_comm", "--report", os.path.join(d, "report.json")] +
-                                (["--emulate_shard", shard] if shard else []) + (["--loader_procs", procs] if procs else []))
+            cli = (["--concat_img_dir", d, "--ckpt_file", os.path.join(d, "w.npz"), "--output_dir", d, "--test_seq", "0",
+                    "--batch_size", str(B), "--force_comm", "--report", os.path.join(d, "report.json")] +
+                   (["--emulate_shard", shard] if shard else []) + (["--loader_procs", procs] if procs else []) + (["--sync_driver"] if sync else []))
+            if fresh:
+                import subprocess
+                subprocess.check_call([sys.executable, "-m", "davo_amd.run_kitti_pose"] + cli, cwd=ROOT)
+            else:
+                run_kitti_pose.main(cli)
             r = json.load(open(os.path.join(d, "report.json")))
             r["process_wall_s_incl_context_and_weights"] = round(time.perf_counter() - t0, 3)
             runs.append(r)
         assert len(open(os.path.join(d, "00-pred_kitti_pose.txt")).read().splitlines()) == N
     rec = {"what": "BASELINE configs[3] shape on ONE rank from files (seq 00: 4541 frames, 4539 windows, batch 64, forced RCCL gather); "
                    "8 ranks would each take 568 of these windows" + (": THIS run is the work of rank %s" % shard if shard else ""),
-           "images": images, "mean_jpeg_bytes_per_strip": jpg_bytes, "runs": runs}
+           "driver": "synchronous (davo_forward per batch)" if sync else "streamed (davo_submit, three batches in flight)",
+           "fresh_process_per_run": fresh, "images": images, "mean_jpeg_bytes_per_strip": jpg_bytes, "runs": runs}
     print(json.dumps(rec, indent=1))
     if out:
         json.dump(rec, open(out, "w"), indent=1)
