@@ -105,9 +105,11 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=32, help="triplets per GPU per step")
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=416)
-    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic windows generated per rank (tiled to the batch)")
-    ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
-                    help="f16x3: split-fp16 MFMA, float32-grade (default); f32: FP32 MFMA, bit-exact fmaf chains")
+    ap.add_argument("--unique", type=int, default=0, help="distinct synthetic windows generated per rank (tiled to the batch); 0 = the whole batch distinct")
+    ap.add_argument("--precision", choices=["f16x3", "f32"], default="f32",
+                    help="arithmetic of the top-level value / roofline.  f32 (default): FP32 MFMA, bit-exact fmaf chains - the reference's own "
+                         "arithmetic (slim.conv2d in float32, nets/posenn.py:205-215); f16x3: split-fp16 MFMA, float32-grade, the library's "
+                         "default mode.  The other one is measured in the same run and nested (fast_mode / reference_arithmetic)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches kept in flight on the GPU in the timed region (davo_set_inflight).  Default 1: one "
                          "batch at a time, so the event-bracketed kernel durations are the kernels' own")
@@ -116,7 +118,8 @@ def parse_args():
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra 2-in-flight throughput measurement (used for the rocprofv3 passes, so that "
                          "per-kernel statistics are not mixed with overlapped launches)")
-    ap.add_argument("--no-f32", action="store_true", help="skip the strict-float32 leg (roofline.reference_arithmetic)")
+    ap.add_argument("--no-f32", "--no-second-leg", dest="no_f32", action="store_true",
+                    help="skip the leg in the OTHER arithmetic (fast_mode when the top level is float32, reference_arithmetic when it is f16x3)")
     ap.add_argument("--profile-stride", type=int, default=0,
                     help="HIP events around the dominant kernel of every n-th timed step (default: 4 when steps >= 40, else 1)")
     ap.add_argument("--options", default="", help="davo_set_option pairs applied before the first step, k=v,k=v (A/B of launch plans under the profiler)")
@@ -156,7 +159,7 @@ def main():
 
     # synthetic windows of this rank's shard, resident in HBM before the timed region; one buffer set per
     # in-flight slot (consecutive steps work on different batches of the shard)
-    nu = max(1, min(args.unique, B))
+    nu = B if args.unique <= 0 else max(1, min(args.unique, B))
     nset = max(1, args.inflight)
     sets = []
     for k in range(nset):
@@ -252,14 +255,12 @@ def main():
             kname = ("davo::%s (cnv6 %s: rotation|translation fused, N=256, K=2304, %s tile, LDS-DMA staged, "
                      "v_mfma_f32_16x16x32_f16)" % ("conv_igemm_h3_mainrem<6,2>" if merged else "conv_igemm_h3<3,1,...,6,true,false,true>",
                                                    "whole layer, one launch" if merged else "main launch", tiles.get(plan[0][1], "?")))
-            peak_note = ("fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP; frac = matrix-pipe utilisation.  Measured "
-                         "beside it (tools/exp/mfma_peak_probe.hip, profiles/r04d_mfma_peak_probe2.log): under the board power cap a loop of "
-                         "nothing but v_mfma_f32_16x16x32_f16 on random operands sustains 2,029-2,046 TFLOP/s (zeros: 2,437-2,465), and one "
-                         "that also reads its operands from LDS at this tile's 0.25 fragment reads per MFMA 1,602 = 0.64 of the nominal peak")
+            peak_note = ("fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP.  What loops of nothing but this matrix "
+                         "instruction sustain under the board power cap is measured in profiles/r04d_mfma_peak_probe{,2}.log and DESIGN.md section 2")
             key = "conv_igemm_h3_mainrem<6" if merged else "conv_igemm_h3<3, 1, "
         # HBM traffic of the dominant kernel: from the most recent committed PMC pass (profiles/), not live —
         # rocprofv3 counter collection cannot run inside the timed process
-        traffic, traffic_src = None, None
+        traffic, traffic_src, busy = None, None, None
         try:
             import glob
             for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))):
@@ -270,57 +271,70 @@ def main():
                 if hit:
                     hit.sort(key=lambda v: -(v["read_bytes"] + v["write_bytes"]))
                     traffic = hit[0]["read_bytes"] + hit[0]["write_bytes"]
+                    busy = round(hit[0]["mfma_busy"], 4) if "mfma_busy" in hit[0] else None
                     traffic_src = "profiles/" + os.path.basename(f)
                     break
         except (OSError, ValueError, KeyError):
             pass
-        ceiling = None
-        if precision != "f32":
-            # what loops of nothing but v_mfma_f32_16x16x32_f16 sustain on this chip class under the board power cap
-            # (tools/exp/mfma_peak_probe.hip; measured on another box of the pool, committed under profiles/): context for `frac`
-            ceiling = {"unit": "TFLOP/s of fp16 products", "this_kernel_products": round(3.0 * achieved, 1),
-                       "pure_mfma_loop_random_operands": 2040.0, "pure_mfma_loop_zero_operands": 2450.0,
-                       "mfma_loop_fed_from_lds_at_this_tiles_ratio": 1602.0,
-                       "frac_of_lds_fed_loop": round(3.0 * achieved / 1602.0, 4),
-                       "source": "profiles/r04d_mfma_peak_probe.log, profiles/r04d_mfma_peak_probe2.log"}
         return {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "measured_ceiling": ceiling, "traffic": traffic,
-                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                "frac": round(achieved / peak, 4), "mfma_busy": busy, "mfma_busy_source": traffic_src if busy is not None else None,
+                "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                 "peak_note": peak_note, "avg_launch_ms": round(avg6, 4), "launches_timed": n6, "flops_per_launch": flops_main,
+                "frac_note": "achieved = NOMINAL dense FLOPs of the launch (SURVEY 8d: padded taps included) / its duration.  The 3x3 kernels "
+                             "skip filter rows that are zero padding for a whole tile, so frac can exceed the fraction of time the matrix "
+                             "pipe is busy: mfma_busy (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, from the committed rocprofv3 PMC pass named "
+                             "beside it, another box) is the utilisation",
                 "launch_plan": "cnv6 as %s (mtiles of 128 rows, N tile)" % plan}
 
-    # the reference's own arithmetic (float32, nets/posenn.py:205-215 slim.conv2d) as a first-class result:
-    # same batch, same K steps, barrier on both sides, max over ranks, its own roofline against the FP32-MFMA peak
-    f32_block = None
-    if args.precision == "f16x3" and not args.no_f32:
-        eng.set_precision("f32")
-        for _ in range(max(2, args.warmup // 10)):
+    # The OTHER arithmetic, in the same process on the same batch: same K steps, same barrier + synchronize bracketing, max over
+    # ranks, its own roofline against the peak of the matrix instruction it uses, its own untimed run-in (the two modes load the chip
+    # differently: float32 runs at full clock, f16x3 at the board power cap).  Top level float32 (default) -> `fast_mode` = f16x3,
+    # the library's default mode; top level f16x3 -> `reference_arithmetic` = float32.
+    other = "f16x3" if args.precision == "f32" else "f32"
+    other_block = None
+    other_kernels = None
+    if not args.no_f32:
+        eng.set_precision(other)
+        for _ in range(args.warmup + settle if other == "f16x3" else max(2, (args.warmup + settle) // 10)):
             eng.forward_device(B, d_img, d_flow, d_seg, d_pose)
         eng.profile(2)
-        eng.set_option("profile_stride", args.profile_stride or (4 if args.steps >= 40 else 1))
+        eng.set_option("profile_stride", stride)
         eng.profile_reset()
-        f32_elapsed = timed(lambda k: [eng.forward_device(B, d_img, d_flow, d_seg, d_pose) for _ in range(k)], args.steps)
-        dom32 = eng.profile_entries()
-        plan32 = eng.last_plan(5)
+        o_elapsed = timed(lambda k: [eng.forward_device(B, d_img, d_flow, d_seg, d_pose) for _ in range(k)], args.steps)
+        dom_o = eng.profile_entries()
+        plan_o = eng.last_plan(5)
+        eng.profile(1)
+        eng.profile_reset()
+        for _ in range(max(3, args.steps // 4)):
+            eng.forward_device(B, d_img, d_flow, d_seg, d_pose)
+        other_kernels = {k: round(v[1] / max(v[0], 1), 4) for k, v in eng.profile_entries().items()}
         eng.profile(False)
-        whole32 = flops_per_triplet * B * args.steps / f32_elapsed / 1e12
-        f32_block = roofline_block("f32", dom32, plan32)
-        f32_block.update({"value": round(world * B * args.steps / f32_elapsed, 2), "unit_value": "triplets/s",
-                          "ms_per_step": round(f32_elapsed / args.steps * 1e3, 4), "steps": args.steps, "dtype": "f32",
-                          "whole_path_tflops_per_gpu": round(whole32, 2),
-                          "whole_path_frac_of_mfma_peak": round(whole32 / PEAK_F32_MFMA_TFLOPS, 4),
-                          "note": "davo_set_precision(0): v_mfma_f32_32x32x2_f32, bit-for-bit float32 fmaf chains — the "
-                                  "reference's arithmetic; same batch, steps and bracketing as `value`"})
-        poses32 = d_pose.download((B, 2, 6))
-        f32_block["max_abs_diff_f16x3_vs_f32"] = float(np.abs(poses32 - poses).max())
-        eng.set_precision("f16x3")
-        eng.forward_device(B, d_img, d_flow, d_seg, d_pose)      # d_pose holds the f16x3 result again
+        eng.synchronize()
+        whole_o = flops_per_triplet * B * args.steps / o_elapsed / 1e12
+        peak_o = PEAK_F32_MFMA_TFLOPS if other == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
+        poses_o = d_pose.download((B, 2, 6))
+        other_block = {"value": round(world * B * args.steps / o_elapsed, 2), "unit": "triplets/s",
+                       "ms_per_step": round(o_elapsed / args.steps * 1e3, 4), "steps": args.steps,
+                       "dtype": "f32" if other == "f32" else "f16x3 (fp16 hi/lo split operands, 3 MFMA products, f32 accumulate)",
+                       "roofline": roofline_block(other, dom_o, plan_o),
+                       "whole_path_tflops_per_gpu": round(whole_o, 2), "whole_path_frac_of_mfma_peak": round(whole_o / peak_o, 4),
+                       "kernel_avg_ms": other_kernels,
+                       "max_abs_diff_f16x3_vs_f32": float(np.abs(poses_o - poses).max()),
+                       "note": ("davo_set_precision(1), the library's default: every float32 operand as an fp16 (hi, lo) pair, three "
+                                "v_mfma_f32_16x16x32_f16 products per product, float32 accumulate - float32-grade poses (max_abs_diff beside "
+                                "this note; the north star's tolerance is 1e-4), narrower arithmetic than the reference's by the letter"
+                                if other == "f16x3" else
+                                "davo_set_precision(0): v_mfma_f32_32x32x2_f32, bit-for-bit float32 fmaf chains - the reference's arithmetic")
+                               + "; same batch, steps and bracketing as `value`"}
+        eng.set_precision(args.precision)
+        eng.forward_device(B, d_img, d_flow, d_seg, d_pose)      # d_pose holds the top-level mode's result again
         eng.synchronize()
 
     # extra, outside `value`: throughput with two batches in flight (the next batch's small kernels overlap this
     # batch's large convolutions; kernel wall durations are then shared time, so no roofline is quoted for it)
     pipelined = None
     if not args.no_pipelined and nset == 1:
+        eng.set_precision("f16x3")                    # the library's default mode: what a streaming caller (davo_submit) runs
         img2, flow2, seg2 = synth.make_inputs(nu, H, W, first_window=(world + rank) * B)
         reps2 = -(-B // nu)
         set2 = (eng.alloc(img.nbytes).upload(np.tile(img2, (reps2, 1, 1, 1))[:B]),
@@ -334,11 +348,12 @@ def main():
         for i in range(args.warmup + settle):
             eng.forward_device(B, *both[i % 2])
         pdt = timed(lambda k: [eng.forward_device(B, *both[i % 2]) for i in range(k)], args.steps)
-        pipelined = {"batches_in_flight": 2, "value": round(world * B * args.steps / pdt, 2), "unit": "triplets/s",
+        pipelined = {"batches_in_flight": 2, "dtype": "f16x3", "value": round(world * B * args.steps / pdt, 2), "unit": "triplets/s",
                      "ms_per_step": round(pdt / args.steps * 1e3, 4), "untimed_steps_before": args.warmup + settle,
                      "note": "davo_set_inflight(ctx, 2); same K steps, same untimed run-in, barrier + synchronize on both sides, max over "
                              "ranks; the next batch's small kernels overlap this batch's large convolutions"}
         eng.set_inflight(1)
+        eng.set_precision(args.precision)
         eng.forward_device(B, *sets[0])
         eng.synchronize()
         sets.append(set2)
@@ -365,17 +380,23 @@ def main():
         kern_ms = {k: round(v[1] / max(v[0], 1), 4) for k, v in kernels.items()}
         whole = flops_per_triplet * B * args.steps / elapsed_max / 1e12
         roof = roofline_block(args.precision, dominant, plan6)
-        # the like-for-like leg (the reference computes in float32, nets/posenn.py:205-215) rides inside `roofline`
-        roof["reference_arithmetic"] = f32_block
         roof["whole_path_frac_of_mfma_peak"] = round(whole / roof["peak"], 4)
-        dtype = "f32" if args.precision == "f32" else "f16x3 (fp16 hi/lo split operands, 3 MFMA products, f32 accumulate)"
+        if other_block is not None:
+            # flat copies inside `roofline` (a reader that keeps only this object's scalars still sees both arithmetics)
+            tag = "fast_mode" if other == "f16x3" else "reference_arithmetic"
+            roof.update({tag + "_value": other_block["value"], tag + "_ms_per_step": other_block["ms_per_step"],
+                         tag + "_frac": other_block["roofline"]["frac"], tag + "_mfma_busy": other_block["roofline"]["mfma_busy"],
+                         tag + "_whole_path_frac_of_mfma_peak": other_block["whole_path_frac_of_mfma_peak"],
+                         tag + "_dtype": other, tag + "_max_abs_diff_vs_top_level": other_block["max_abs_diff_f16x3_vs_f32"]})
+        dtype = ("f32 (v_mfma_f32_32x32x2_f32: the reference's arithmetic, slim.conv2d in float32)" if args.precision == "f32"
+                 else "f16x3 (fp16 hi/lo split operands, 3 MFMA products, f32 accumulate)")
         # the HBM-bound front of the path: algorithmic bytes / kernel time from the per-kernel breakdown pass
         sq_ms, mp_ms = kern_ms.get("se_squeeze_partial", 0.0), kern_ms.get("mask_pack", 0.0)
         pro_bytes = (SQUEEZE_BYTES_128x416 + PACK_BYTES_128x416) * scale_px * B
         pro = None
         if sq_ms > 0 and mp_ms > 0:
             gbs = pro_bytes / ((sq_ms + mp_ms) * 1e-3) / 1e9
-            pro = {"bound": "hbm", "kernels": "se_squeeze_partial + mask_pack<16>", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+            pro = {"bound": "hbm", "kernels": "se_squeeze_partial + mask_pack<%d>" % (8 if args.precision == "f32" else 16), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                    "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_step": int(pro_bytes),
                    "ms": round(sq_ms + mp_ms, 4),
                    "parts": {"se_squeeze_partial": {"bytes": int(SQUEEZE_BYTES_128x416 * scale_px * B), "ms": sq_ms,
@@ -383,7 +404,7 @@ def main():
                              "mask_pack": {"bytes": int(PACK_BYTES_128x416 * scale_px * B), "ms": mp_ms,
                                            "GB/s": round(PACK_BYTES_128x416 * scale_px * B / (mp_ms * 1e-3) / 1e9, 1)}},
                    "note": "algorithmic bytes: flow planes 0,1 (squeeze); u8 strip + 2 flow + 2 seg planes in, packed "
-                           "[2B,H,W,8 hi|8 lo] out (mask_pack); peak = 8 TB/s HBM3E spec"}
+                           "[2B,H,W,8] float32 (f16x3: 8 hi | 8 lo halves, the same 32 B per pixel) out (mask_pack); peak = 8 TB/s HBM3E spec"}
         res = {
             "metric": "pose-net triplets/sec (128x416x3-frame)" if (H, W) == (128, 416)
                       else "pose-net triplets/sec (%dx%dx3-frame)" % (H, W),
@@ -397,6 +418,7 @@ def main():
                        "parallelism": "window-sharded replicas x%d" % world, "batches_in_flight": nset,
                        **({"options": args.options} if args.options else {})},
             "roofline": roof,
+            ("fast_mode" if other == "f16x3" else "reference_arithmetic"): other_block,
             "timing": timing,
             "whole_path_tflops_per_gpu": round(whole, 2),
             "whole_path_frac_of_mfma_peak": round(whole / roof["peak"], 4),

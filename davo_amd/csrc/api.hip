@@ -16,6 +16,15 @@ using namespace davo;
 
 namespace {
 
+// hipMemset runs on the null stream and may return before the fill has run; the context's streams are non-blocking, so nothing
+// orders them behind it.  (Found as one wrong batch in twenty streamed runs: the zero fill of a slot's new staging set landed on
+// top of the first batch's freshly copied flow planes, profiles/r05f_stream_flake.log.)  Returns when the bytes ARE zero.
+int zero_now(davo_ctx* c, void* p, size_t bytes) {
+    HIP_TRY(c, hipMemset(p, 0, bytes));
+    HIP_TRY(c, hipStreamSynchronize(nullptr));
+    return DAVO_OK;
+}
+
 void free_slot(Slot& s) {
     for (auto p : s.d_act) if (p) (void)hipFree(p);
     void* misc[] = {s.d_partial, s.d_tab, s.d_packed, s.d_pose_partial, s.d_counters};
@@ -34,9 +43,9 @@ int alloc_slot(davo_ctx* c, Slot* s) {
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_partial), (size_t)c->max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_tab), (size_t)c->max_batch * 3 * NCLS * sizeof(float)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_pose_partial), NB * 2 * PH_SPLIT * 3 * sizeof(float)));
-    HIP_TRY(c, hipMemset(s->d_partial, 0, (size_t)c->max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)));
+    { int rc = zero_now(c, s->d_partial, (size_t)c->max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)); if (rc) return rc; }
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_counters), ((size_t)c->max_batch + 1) * sizeof(unsigned)));
-    HIP_TRY(c, hipMemset(s->d_counters, 0, ((size_t)c->max_batch + 1) * sizeof(unsigned)));
+    { int rc = zero_now(c, s->d_counters, ((size_t)c->max_batch + 1) * sizeof(unsigned)); if (rc) return rc; }
     return DAVO_OK;
 }
 
@@ -95,9 +104,9 @@ int davo_create(davo_ctx** out, int device, int H, int W, int max_batch, const d
     c->own_stream = c->slots[0].stream;
     activate_slot(c, 0);
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_zeros), 256));
-    HIP_TRY(c, hipMemset(c->d_zeros, 0, 256));
+    { int rc = zero_now(c, c->d_zeros, 256); if (rc) return rc; }
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_range_base), (1 + RANGE_RING) * RANGE_WORDS * sizeof(unsigned)));
-    HIP_TRY(c, hipMemset(c->d_range_base, 0, (1 + RANGE_RING) * RANGE_WORDS * sizeof(unsigned)));
+    { int rc = zero_now(c, c->d_range_base, (1 + RANGE_RING) * RANGE_WORDS * sizeof(unsigned)); if (rc) return rc; }
     c->d_range = c->d_range_base;
     return DAVO_OK;
 }
@@ -219,7 +228,7 @@ int freeze_pending_and_reset_ring(davo_ctx* c) {
             memcpy(t.raw, m, sizeof t.raw);
             t.frozen = true;
         }
-    HIP_TRY(c, hipMemset(c->d_range_base + RANGE_WORDS, 0, RANGE_RING * RANGE_WORDS * sizeof(unsigned)));
+    { int rc = zero_now(c, c->d_range_base + RANGE_WORDS, RANGE_RING * RANGE_WORDS * sizeof(unsigned)); if (rc) return rc; }
     return DAVO_OK;
 }
 
@@ -523,8 +532,8 @@ int ensure_stream_state(davo_ctx* c, int slot) {
         HIP_TRY(c, hipMalloc(&c->st_flow[slot], flow_bytes(c) * c->max_batch));
         HIP_TRY(c, hipMalloc(&c->st_seg[slot], seg_bytes(c) * c->max_batch));
         // planes the path never reads (flow 2,3; the target frame's label map) are never copied either: defined contents all the same
-        HIP_TRY(c, hipMemset(c->st_flow[slot], 0, flow_bytes(c) * c->max_batch));
-        HIP_TRY(c, hipMemset(c->st_seg[slot], 0, seg_bytes(c) * c->max_batch));
+        { int rc = zero_now(c, c->st_flow[slot], flow_bytes(c) * c->max_batch); if (rc) return rc; }
+        { int rc = zero_now(c, c->st_seg[slot], seg_bytes(c) * c->max_batch); if (rc) return rc; }
     }
     return DAVO_OK;
 }

@@ -102,8 +102,19 @@ def main(argv=None):
         preload_in_background()
     import threading
     loader_thread = None
-
     H, W = a.img_height, a.img_width
+    # the GPU context first: the communicator's thread needs it, and HIP's own initialisation (0.3-0.4 s) is on every path
+    from . import _lib
+    _lib.lib()
+    mark("library_loaded")
+    system = DAVO(version=a.version, device=device_index)
+    system.setup_inference(H, W, "davo", a.seq_length, a.batch_size)
+    mark("gpu_context_created")
+    # the communicator is not needed before the gather: the id exchange and ncclCommInitRank (1.5-1.7 s, most of it inside HIP's
+    # code-object loading, which other HIP calls queue behind) run on a second thread from here on (collective; fails loudly at the
+    # gather, no other transport)
+    comm = RcclComm.from_env_async(system.engine) if need_comm else None
+
     if a.synthetic:
         from . import synth
         n_frames = a.synthetic
@@ -135,24 +146,15 @@ def main(argv=None):
                                      pin=lambda arr: pin_array(arr, device_index), unpin=unpin_array,
                                      seg_planes=(0, 1, 2) if static_all else None, hold=0 if a.sync_driver else 1)
         # the loader's buffers are created and page-locked (1.4 GB at batch 64: 0.2-0.3 s) and its workers start filling them on a
-        # thread of its own while the checkpoint is read and the GPU context is built
+        # thread of its own while the checkpoint is read and packed for the GPU
         shard = S.shard_windows(n_frames - 2, *((world, rank) if emulate is None else (emulate[1], emulate[0])))
         loader_thread = threading.Thread(target=load.prestart, args=(shard[0], shard[1], a.batch_size), name="davo-loader-start")
         loader_thread.start()
         from .tf_checkpoint import load_weights
         weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
     mark("inputs_and_weights_ready")
-
-    system = DAVO(version=a.version, device=device_index)
     system.load_weights(weights)
-    from . import _lib
-    _lib.lib()
-    mark("library_loaded")
-    system.setup_inference(H, W, "davo", a.seq_length, a.batch_size)
-    mark("context_and_weights_on_gpu")
-    # the communicator is not needed before the gather: the id exchange and ncclCommInitRank run on a second thread from here on
-    # (collective; fails loudly at the gather, no other transport)
-    comm = RcclComm.from_env_async(system.engine) if need_comm else None
+    mark("weights_on_gpu")
     infer = lambda img, flow, seg: system.inference(None, "pose", inputs=(img, flow, seg))["pose"]   # noqa: E731
     if not a.no_calibrate:
         # every rank calibrates on the same first windows, so the trajectory does not depend on the world size.  Eight windows at

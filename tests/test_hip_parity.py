@@ -491,18 +491,26 @@ def test_config2_batch32_full_size(c_oracle):
     e.close()
 
 
-def test_config3_batch128_properties(c_oracle):
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_config3_batch128_properties(c_oracle, precision):
     """configs[2]: B=128 — 16 distinct windows tiled 8x: duplicates must produce identical poses
-    wherever they sit in the batch (any tile, any launch of the plan), and a sample matches the oracle."""
+    wherever they sit in the batch (any tile, any launch of the plan), and a sample matches the oracle.  Both arithmetic modes
+    (float32 = the reference's own, with its per-launch tile orders and filter-row ranges at this batch), and both ways of
+    issuing the batch: as davo_forward's sub-batches of eight and in ONE piece (the launch plan of a resident batch of 128)."""
     cfg = parse_version(FLAGSHIP_VERSION)
     img16, flow16, seg16 = synth.make_inputs(16, 128, 416, first_window=500)
     weights = synth.make_weights(cfg)
     img, flow, seg = np.tile(img16, (8, 1, 1, 1)), np.tile(flow16, (8, 1, 1, 1, 1)), np.tile(seg16, (8, 1, 1, 1, 1))
-    e = _engine(cfg, 128, 416, 128, weights, "f16x3")
-    got = e.forward(img, flow, seg).reshape(8, 16, 2, 6)
-    for r in range(1, 8):                                    # fused pose head: equal to float32 rounding (see above)
-        assert np.abs(got[r] - got[0]).max() <= 1e-6 * np.abs(got[0]).max()
-    assert_pose_close(got[0, :4], c_oracle.forward(cfg, img16[:4], flow16[:4], seg16[:4], weights), "B=128 sample")
+    want = c_oracle.forward(cfg, img16[:4], flow16[:4], seg16[:4], weights)
+    e = _engine(cfg, 128, 416, 128, weights, precision)
+    for chunk in (8, 0):
+        e.set_option("host_chunk", chunk)
+        got = e.forward(img, flow, seg).reshape(8, 16, 2, 6)
+        for r in range(1, 8):                                    # fused pose head: equal to float32 rounding (see above)
+            assert np.abs(got[r] - got[0]).max() <= 1e-6 * np.abs(got[0]).max()
+        assert_pose_close(got[0, :4], want, "B=128 sample, %s, host_chunk %d" % (precision, chunk))
+        if chunk == 0:
+            assert sum(m for m, _ in e.last_plan(5)) == 128 * 2 * 32 * 104 // 128       # cnv6's launches cover all 256 pair images of ONE batch
     e.close()
 
 
@@ -732,21 +740,32 @@ def test_config4_eight_shards_equal_one(c_oracle):
     assert np.array(S.stitch_trajectory(eight)).shape == (4541, 4, 4)
     for w in (0, 567, 568, 3975, 3976, 4538):
         assert_pose_close(eight[w:w + 1], c_oracle.forward(cfg, *load(w, w + 1), weights), "window %d" % w)
+    # one rank's shard in the reference's own arithmetic, batches issued whole (the float32 launch plan at batch 64 and at the
+    # shard's ragged last batch of 56 -> padded to 64)
+    e.set_precision("f32")
+    e.set_option("host_chunk", 0)
+    lo, hi = S.shard_windows(nw, 8, 3)
+    shard = S.run_shard(e.forward, load, lo, hi, B)
+    assert np.abs(shard - one[lo:hi]).max() <= 2e-6 * np.abs(one).max()             # the two modes agree to float32 rounding
+    for w in (lo, lo + 63, lo + 64, hi - 1):
+        assert_pose_close(shard[w - lo:w - lo + 1], c_oracle.forward(cfg, *load(w, w + 1), weights), "float32, window %d" % w)
     e.close()
 
 
-def test_config5_per_gpu_plan_256x832_batch64(c_oracle):
-    """configs[4] per-GPU shape: 256x832, B=64 (activations past 2^32 bytes, the full launch plan): 8 distinct
-    windows tiled 8x — duplicates must agree wherever they sit in the batch, and two windows match the oracle."""
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_config5_per_gpu_plan_256x832_batch64(c_oracle, precision):
+    """configs[4] per-GPU shape: 256x832, B=64 (activations past 2^32 bytes, the full launch plan, issued in one piece): 8 distinct
+    windows tiled 8x — duplicates must agree wherever they sit in the batch, and two windows match the oracle; in both modes."""
     cfg = parse_version(FLAGSHIP_VERSION)
     img8, flow8, seg8 = synth.make_inputs(8, 256, 832, first_window=40)
     weights = synth.make_weights(cfg)
     img, flow, seg = np.tile(img8, (8, 1, 1, 1)), np.tile(flow8, (8, 1, 1, 1, 1)), np.tile(seg8, (8, 1, 1, 1, 1))
-    e = _engine(cfg, 256, 832, 64, weights, "f16x3")
+    e = _engine(cfg, 256, 832, 64, weights, precision)
+    e.set_option("host_chunk", 0)
     got = e.forward(img, flow, seg).reshape(8, 8, 2, 6)
     for r in range(1, 8):
         assert np.abs(got[r] - got[0]).max() <= 1e-6 * np.abs(got[0]).max()
-    assert_pose_close(got[0, :2], c_oracle.forward(cfg, img8[:2], flow8[:2], seg8[:2], weights), "256x832 B=64 sample")
+    assert_pose_close(got[0, :2], c_oracle.forward(cfg, img8[:2], flow8[:2], seg8[:2], weights), "256x832 B=64 sample, %s" % precision)
     e.close()
 
 

@@ -86,6 +86,9 @@ def main():
         for k in sorted(set(fe) | set(wr)):
             f = fe[k].get("FETCH_SIZE", []); w = wr[k].get("WRITE_SIZE", [])
             tr[k] = {"read_bytes": 2 * (sum(f) / len(f) if f else 0.0) * 1024, "write_bytes": (sum(w) / len(w) if w else 0.0) * 1024}
+            c = {n: sum(v) / len(v) for n, v in sq.get(k, {}).items()} if sq else {}
+            if c.get("GRBM_GUI_ACTIVE"):        # matrix pipe busy fraction of the launch (SQ pass), beside its traffic: bench.py quotes both
+                tr[k]["mfma_busy"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * c["GRBM_GUI_ACTIVE"] / 8)
         json.dump({"source": os.path.basename(a.out), "batch": a.batch, "note": "per launch; FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE exact",
                    "kernels": tr}, open(a.out + "_traffic.json", "w"), indent=1)
     open(a.out + "_summary.md", "w").write("\n".join(lines))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end measurement set, run ON the GPU box:   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02a'
-# Leaves under gpurun_out/: bench_<tag>32.json (full bench line incl. cpu_baseline and roofline_f32), bench_<tag>128.json,
+# Leaves under gpurun_out/: bench_<tag>32.json (full bench line: float32 top level, f16x3 nested as fast_mode, cpu_baseline), bench_<tag>128.json,
 # bench_<tag>64_256x832.json, and the rocprofv3 directories prof_{stats,fetch,write,sq}[_b128], which
 #   python tools/prof_summary.py --stats gpurun_out/prof_stats --fetch gpurun_out/prof_fetch \
 #       --write gpurun_out/prof_write --sq gpurun_out/prof_sq --out profiles/<tag>_bench_b32_f16x3
@@ -18,7 +18,7 @@ python3 "$R/bench.py" > "$O/bench_${TAG}32.json" 2> "$O/bench_${TAG}32.err"; ech
 python3 "$R/bench.py" --batch 128 --no-cpu-baseline > "$O/bench_${TAG}128.json" 2>/dev/null
 python3 "$R/bench.py" --height 256 --width 832 --batch 64 --no-cpu-baseline > "$O/bench_${TAG}64_256x832.json" 2>/dev/null
 for f in 32 128 64_256x832; do
-  python3 -c "import json; d=json.loads(open('$O/bench_${TAG}$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['whole_path_frac_of_mfma_peak'], d['pipelined']['value'], (d['roofline'].get('reference_arithmetic') or {}).get('value'))"
+  python3 -c "import json; d=json.loads(open('$O/bench_${TAG}$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['whole_path_frac_of_mfma_peak'], d['pipelined']['value'], (d.get('fast_mode') or d.get('reference_arithmetic') or {}).get('value'), (d.get('fast_mode') or d.get('reference_arithmetic') or {}).get('whole_path_frac_of_mfma_peak'))"
 done
 cd /tmp
 rm -rf "$O"/prof_*
