@@ -44,8 +44,8 @@ int alloc_slot(davo_ctx* c, Slot* s) {
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_tab), (size_t)c->max_batch * 3 * NCLS * sizeof(float)));
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_pose_partial), NB * 2 * PH_SPLIT * 3 * sizeof(float)));
     { int rc = zero_now(c, s->d_partial, (size_t)c->max_batch * 2 * SQ_CHUNKS * 2 * sizeof(float)); if (rc) return rc; }
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_counters), ((size_t)c->max_batch + 1) * sizeof(unsigned)));
-    { int rc = zero_now(c, s->d_counters, ((size_t)c->max_batch + 1) * sizeof(unsigned)); if (rc) return rc; }
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&s->d_counters), ((size_t)c->max_batch + 1 + SK_TILE_COUNTERS) * sizeof(unsigned)));
+    { int rc = zero_now(c, s->d_counters, ((size_t)c->max_batch + 1 + SK_TILE_COUNTERS) * sizeof(unsigned)); if (rc) return rc; }
     return DAVO_OK;
 }
 
@@ -949,6 +949,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "fold_tails") c->opt_fold_tails = value < 0 ? -1 : (value > 2 ? 1 : value);
     else if (k == "deep_ring") c->opt_deep_ring = value != 0;
     else if (k == "split_k") c->opt_split_k = value != 0;
+    else if (k == "fold_fixup") c->opt_fold_fixup = value != 0;
     else if (k == "f32_n16") c->opt_f32_n16 = value != 0;
     else if (k == "patch_f32") c->opt_patch_f32 = value != 0;
     else if (k == "auto_range") { int rc = judge_all(c); if (rc) return rc; c->opt_auto_range = value != 0; }

@@ -905,6 +905,8 @@ __device__ __forceinline__ void conv_igemm_h3_body(const ConvParamsH& p, const i
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
         range_note(p.range, vmax, lane == 0);      // params.h: only a wave that would raise the record pays for the atomic
     }
+    // split-K part with the fix-up folded in: the tile's last part adds the partial sums and writes the stored form (pose_tail.h)
+    if (p.y_mode == 0 && p.sk_counter) splitk_tail<WM * WN * 64, BMH, BNH>(p, mtile, ntile, reinterpret_cast<unsigned*>(smem_h));
 }
 
 template <int KS, int STRIDE, int WM, int WN, int TM, int TN, int LAYER, bool DMA, bool SMALLC, bool M16 = false, int NSTG = 2, int RATE = 0>

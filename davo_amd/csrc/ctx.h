@@ -64,7 +64,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     float *d_partial = nullptr, *d_tab = nullptr, *d_packed = nullptr, *d_pose_partial = nullptr;
     float* d_act[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    unsigned* d_counters = nullptr;              // "last workgroup" tickets (pose_tail.h): [0] cnv7's pose tail, [1 + b] triplet b's squeeze
+    unsigned* d_counters = nullptr;              // "last workgroup" tickets (pose_tail.h): [0] cnv7's pose tail, [1 + b] triplet b's squeeze, [1 + max_batch + t] tile t of a split-K launch
 };
 
 // A batch davo_forward_device has issued whose f16x3 range record has not been judged yet.  Every such batch owns one slot of a
@@ -72,6 +72,7 @@ struct Slot {
 // its inputs, which the batch's last kernel fills if (and only if) the record will fail the verdict, so that the re-issue reads
 // exactly what was issued whatever the caller has done to its buffers since (api.hip, prologue.h).
 constexpr int RANGE_RING = 8;
+constexpr int SK_TILE_COUNTERS = 256;            // tiles of a split-K launch whose fix-up is folded in (forward.hip): at most one per CU
 struct Ticket {
     int B;
     const void *img, *flow, *seg;              // what a re-issue reads: the ring slot's snapshot, or the caller's buffers ("stable_inputs")
@@ -127,6 +128,8 @@ struct davo_ctx {
     bool opt_merge_cnv4 = false;               // f16x3: cnv4 as whole rounds of 256x128 tiles + 128x128 remainder tiles in one grid where the batch allows
     bool opt_share_taps = true;                // f16x3: cnv3..cnv6 stage one pixel patch per filter row for its three taps
     bool opt_f32_n16 = true;                   // f32 mode: cnv1 (16 output channels) on the 128x16 tile / v_mfma_f32_16x16x4_f32 instead of the padded 128x32 one
+    bool opt_fold_fixup = false;               // f16x3 split-K: the part that finishes a tile last adds its partial sums (no splitk_fixup launch); needs xcd_rr > 0.  Measured slower (batch 1: 0.141 against 0.132 ms): off
+    int xcd_rr = -1;                           // workgroups (x, y) of a grid whose x extent is a multiple of 8 share an XCD for every y: -1 not probed yet | 0 no | 1 yes
     bool opt_split_k = true;                   // f16x3: cnv5 / cnv6 launches of at most half a workgroup per CU split their K loop in two (forward.hip)
     float* d_splitk = nullptr;                 // split-K partial sums [4 slots][M][2][N] float32
     size_t splitk_floats = 0;                  // ... per slot

@@ -332,9 +332,24 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
             dim3 grid(mtiles * ntn, S);
             ps.deep = c->opt_deep_ring && tiles * S <= c->ncu;
             c->last_plan[li][0] = ((p.M + 127) / 128) * 1000 + plan[0].tile;
+            // The fix-up folded into the launch (pose_tail.h, splitk_tail): with an x extent that is a multiple of 8 the S parts of a
+            // tile run on one XCD, so the part that finishes last finds the others' partial sums in its own L2 and writes the stored
+            // form itself - no splitk_fixup launch (7 us each at batch 1, two per forward).  Checked once per context on the device.
+            bool fold = c->opt_fold_fixup && S <= 4 && grid.x % 8 == 0 && (int)grid.x <= SK_TILE_COUNTERS && c->ncu == c->dev_cus && !c->cu_partition &&
+                        !c->user_stream;
+            if (fold && c->xcd_rr < 0) {
+                int ok = 0;
+                HIP_TRY(c, xcd_round_robin_probe(c->stream, &ok));
+                c->xcd_rr = ok;
+            }
+            fold = fold && c->xcd_rr > 0;
+            if (fold) {
+                ps.sk_counter = c->d_counters + 1 + c->max_batch;
+                ps.sk_y = p.y; ps.sk_range = p.range; ps.sk_parts = S; ps.sk_relu = 1;
+            }
             ProfScope pscope(c, L.label);
             HIP_TRY(c, launch_layer_h3(li, plan[0].tile, ps, grid, c->stream));
-            HIP_TRY(c, launch_splitk_fixup(part, p.M, L.cout, S, 1, p.y, p.range, c->stream));
+            if (!fold) HIP_TRY(c, launch_splitk_fixup(part, p.M, L.cout, S, 1, p.y, p.range, c->stream));
             return DAVO_OK;
         }
     }

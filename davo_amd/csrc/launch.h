@@ -37,6 +37,8 @@ hipError_t launch_se_squeeze(const float* d_flow, int B, int HW, const Variant& 
 hipError_t launch_se_excite(const float* d_partial, int B, int HW, const Variant& v, const float* w1, const float* b1,
                             const float* w2, const float* b2, const float* wstatic, float* d_tab, unsigned* d_range_reset, hipStream_t s);
 // squeeze + excitation in one launch: the last workgroup of each triplet evaluates its tables (prologue.h, pose_tail.h);
+// -> 1 if the parts (x, 0..3) of a 64 x 4 grid ran on one XCD each for every x (what the folded split-K fix-up relies on), 0 if not
+hipError_t xcd_round_robin_probe(hipStream_t s, int* ok);
 // d_counters: one zeroed unsigned per triplet, left at zero
 hipError_t launch_se_squeeze_excite(const float* d_flow, int B, int HW, const Variant& v, float* d_partial, unsigned* d_counters,
                                     const float* w1, const float* b1, const float* w2, const float* b2, const float* wstatic,

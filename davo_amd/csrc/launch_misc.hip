@@ -99,6 +99,31 @@ hipError_t launch_cnv3_patch(const ConvPatchParams& p, int nblk, hipStream_t s) 
     return hipGetLastError();
 }
 
+// every workgroup records the XCD it runs on (HW_REG_XCC_ID)
+__global__ __launch_bounds__(64) void xcd_probe_kernel(unsigned* out) {
+    if (threadIdx.x == 0) out[blockIdx.y * gridDim.x + blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;
+}
+
+hipError_t xcd_round_robin_probe(hipStream_t s, int* ok) {
+    constexpr int NX = 64, NY = 4;
+    unsigned* d = nullptr;
+    unsigned h[NX * NY];
+    *ok = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), sizeof h);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3(NX, NY), dim3(64), 0, s, d);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return e;
+    bool same = true;
+    for (int y = 1; y < NY; ++y)
+        for (int x = 0; x < NX; ++x) same = same && h[y * NX + x] == h[x];
+    *ok = same ? 1 : 0;
+    return hipSuccess;
+}
+
 hipError_t launch_splitk_fixup(const float* d_part, long M, int N, int S, int relu, uint8_t* d_y, unsigned* d_range, hipStream_t s) {
     if (N < 32 || N % 32 || S < 2 || M < 1) return hipErrorInvalidValue;
     const long pairs = M * (N / 2);

@@ -129,6 +129,12 @@ struct ConvParamsH {
                             // pixels RATE before and after a tile, which may belong to the layer's other launch
     int xs;                 // host: issue the shared-tap instantiation (conv_igemm_h3 RATE > 0) where the layer has one
     int deep;               // host: the launch has at most one workgroup per CU - issue the deep-ring instantiation of its tile
+    // split-K with the fix-up folded into the launch (pose_tail.h, splitk_tail): the part that finishes last on a tile adds the tile's
+    // sk_parts partial sums (y = float32 [M][sk_parts][Cout]) in fixed order and writes the stored form to sk_y; null = no fold
+    unsigned* sk_counter;   // one ticket counter per tile of the launch (zero before and after)
+    uint8_t* sk_y;          // the layer's split-fp16 blocked output
+    unsigned* sk_range;     // range record word of the layer (or null)
+    int sk_parts, sk_relu;
     int g_x_boff, g_y_coff;
     long g_w, g_bias;
     float out_scale;        // 2^(shift_out - shift_in) / (power of two the layer's weights were multiplied by)

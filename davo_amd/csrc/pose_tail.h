@@ -76,4 +76,72 @@ __device__ __forceinline__ void pose_from_tiles_tail(const ConvParamsH& p) {
     if (threadIdx.x == 0) __hip_atomic_store(p.pose_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+
+// ---- split-K: the fix-up folded into the launch (batch 1: two 7 us launches fewer per forward) -----------------------------
+// The S parts of a tile are the workgroups (x, 0..S-1) of a grid whose x extent is a multiple of 8, and workgroup ids go round-robin
+// over the 8 XCDs (tools/exp/dispatch_probe.hip; checked once per context by xcd_round_robin_probe): ALL parts of a tile run on ONE
+// XCD and their partial sums meet in that XCD's L2.  So, unlike the tails above, nothing has to cross to the memory side: plain
+// stores, a wait for their acknowledgement (the L2 has them), a ticket, and the part that takes the last ticket reads the tile's
+// partial sums back through the same L2 (its CU's vector cache is invalidated first), adds them in the fix-up kernel's fixed order
+// (prologue.h: splitk_fixup - the same bits), applies ReLU, writes the stored form and notes the range.
+template <int THREADS, int BMH, int BNH>
+__device__ __forceinline__ void splitk_tail(const ConvParamsH& p, int mtile, int ntile, unsigned* ticket_lds) {
+    agent_stores_done();                                       // this thread's partial sums are in the L2
+    const int tile = (mtile - p.mtile0) * p.ntiles_n + ntile;
+    if (!last_workgroup(p.sk_counter + tile, (unsigned)p.sk_parts, ticket_lds)) return;
+    asm volatile("buffer_inv sc1" ::: "memory");               // nothing stale in this CU's vector cache
+    const float* __restrict__ part = reinterpret_cast<const float*>(p.y);
+    const int S = p.sk_parts, N = p.Cout;
+    const int m0 = mtile * BMH, n0 = ntile * BNH;
+    const float lo_clamp = p.sk_relu ? 0.f : -65504.f;
+    float vmax = 0.f;
+    // A thread owns four channels (one float4) of every (THREADS / (BNH / 4))-th row.  The loop is all latency if a row's S loads are
+    // issued one after the other (first version: +16 us per layer instead of -7): RU rows x S parts are requested before the first
+    // addition.  Per element the additions are the fix-up kernel's: ((p0 + p1) + p2) + p3.
+    constexpr int C4 = BNH / 4, RSTEP = THREADS / C4, RU = 4;
+    static_assert(THREADS % C4 == 0 && BMH % (RSTEP * RU) == 0, "split-K tail: tile / workgroup shape");
+    const int c4 = threadIdx.x % C4, rbase = threadIdx.x / C4;
+    const int n = n0 + 4 * c4;
+    const bool n_ok = n + 3 < N;                                     // N is a multiple of 32: four channels are in or out together
+    for (int r0 = rbase; r0 < BMH; r0 += RSTEP * RU) {
+        float4 v[RU][4];
+#pragma unroll
+        for (int i = 0; i < RU; ++i) {
+            const long m = m0 + r0 + i * RSTEP;
+            const bool ok = n_ok && m < p.M;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                v[i][s] = (ok && s < S) ? *reinterpret_cast<const float4*>(part + (m * S + s) * N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < RU; ++i) {
+            const long m = m0 + r0 + i * RSTEP;
+            if (!(n_ok && m < p.M)) continue;
+            float x[4] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w};
+#pragma unroll
+            for (int s = 1; s < 4; ++s)
+                if (s < S) { x[0] += v[i][s].x; x[1] += v[i][s].y; x[2] += v[i][s].z; x[3] += v[i][s].w; }
+            unsigned short hi[4], lo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = fmaxf(x[k], lo_clamp);
+                vmax = fmaxf(vmax, fabsf(t));
+                t = fminf(t, 65504.f);
+                const _Float16 h = (_Float16)t;
+                hi[k] = __builtin_bit_cast(unsigned short, h);
+                lo[k] = __builtin_bit_cast(unsigned short, (_Float16)(t - (float)h));
+            }
+            uint8_t* o = p.sk_y + m * (long)N * 4 + (n >> 5) * 128 + (n & 31) * 2;
+            *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+            *reinterpret_cast<uint2*>(o + 64) = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+        }
+    }
+    if (p.sk_range) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        range_note(p.sk_range, vmax, (threadIdx.x & 63) == 0);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(p.sk_counter + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace davo

@@ -237,6 +237,12 @@ const char* davo_range_report(const davo_ctx* ctx);
  *       layer's outputs - and so the poses - agree with the single chain to float32 rounding (~1e-7 relative), not to the
  *       bit; 0 = one K chain at every batch size (poses then do not depend on how windows are batched, with "fuse_pose" 0
  *       to the bit).
+ *   "fold_fixup" (default 0): with "split_k", the part of a tile that finishes last adds the tile's partial sums and writes the stored
+ *       form itself, so the two fix-up launches of a batch-1 forward (7 us each) go: the parts of a tile are the workgroups (x, 0..S-1)
+ *       of a grid whose x extent is a multiple of 8, workgroup ids go round-robin over the XCDs (checked on the device once per
+ *       context), so the partial sums meet in one XCD's L2.  Same additions in the same order: bit-identical to 0.  Measured SLOWER
+ *       (batch 1: 0.141 against 0.132 ms per forward, profiles/r05k_fold_fixup_ab.md): one workgroup per tile adds what the fix-up
+ *       launch spreads over the whole chip, behind a ticket's memory-side round trip; kept for experiments.
  *   "f32_n16" (default 1; float32 mode): cnv1 (16 output channels) on a 128x16 tile with v_mfma_f32_16x16x4_f32 instead of the
  *       128x32 tile whose matrix instructions were half padding.  Another order of the same float32 fma chain per output.
  *   "patch_f32" (default 1; float32 mode): cnv1, cnv2 and cnv3 from an LDS-staged input patch on v_mfma_f32_16x16x4_f32

@@ -1472,6 +1472,47 @@ def test_split_k_small_batches(c_oracle, B, H, W):
     e.close()
 
 
+def test_folded_split_k_fixup_is_bit_identical(c_oracle):
+    """"fold_fixup": at batch 1 (128x416: 104 tiles x 4 parts per layer, an x extent that is a multiple of 8) the part of a tile that
+    finishes last adds the tile's partial sums itself - found in its own XCD's L2 - instead of a splitk_fixup launch.  Same
+    additions in the same order: cnv5, cnv6 and the poses carry the same bits as with the launch, forward after forward, with
+    three batches in flight (the slots' partial-sum regions and ticket counters are their own), and the range record is kept."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    H, W = 128, 416
+    weights = synth.make_weights(cfg)
+    data = [synth.make_inputs(1, H, W, first_window=5 * k) for k in range(4)]
+    e = _engine(cfg, H, W, 1, weights, "f16x3")
+    shp = (2, 32, 104, 256)
+    e.set_option("fold_fixup", 0)
+    want, acts = [], []
+    for d in data:
+        want.append(e.forward(*d).copy())
+        acts.append((e.debug_read("cnv5", shp).copy(), e.debug_read("cnv6", shp).copy()))
+    e.profile(1); e.profile_reset()
+    e.forward(*data[0])
+    assert any("cnv5" == k or "cnv6" == k for k in e.profile_entries())
+    e.profile(0)
+    e.set_option("fold_fixup", 1)                 # (off by default: measured slower than the launch it saves, davo_hip.h)
+    e.activation_range(reset=True)
+    for rep in range(10):
+        for k, d in enumerate(data):
+            got = e.forward(*d)
+            assert np.array_equal(got, want[k]), (rep, k, np.abs(got - want[k]).max())
+            if rep == 0:
+                assert np.array_equal(e.debug_read("cnv5", shp), acts[k][0]) and np.array_equal(e.debug_read("cnv6", shp), acts[k][1])
+    mx, _ = e.activation_range()
+    assert mx["cnv5"] > 0 and mx["cnv6"] > 0                               # the folded tail keeps the range record
+    assert_pose_close(want[0], c_oracle.forward(cfg, *data[0], weights), "batch 1, folded fix-up")
+    e.set_inflight(3)
+    outs = [np.empty((1, 2, 6), np.float32) for _ in range(40)]
+    for i, o in enumerate(outs):
+        e.submit(*data[i % 4], o)
+    e.synchronize()
+    for i, o in enumerate(outs):
+        assert np.array_equal(o, want[i % 4]), i
+    e.close()
+
+
 def test_per_channel_spread_beyond_the_pair_format_runs_in_float32(c_oracle):
     """Half of cnv3's and cnv5's channels at 2^-22 of their neighbours (consumer weights x 2^22): per-layer storage scales
     cannot keep those channels' fp16 pairs float32-grade (measured 9e-4 against the 1e-4 bar).  The spread shows in the
