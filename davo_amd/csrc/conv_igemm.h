@@ -29,6 +29,12 @@
 #define DAVO_F32_ABLATE_A 0    /* timing experiments only: every pixel load reads the zero line / every weight load the first chunk */
 #define DAVO_F32_ABLATE_B 0
 #endif
+#ifndef DAVO_F32_EARLY_STORE
+#define DAVO_F32_EARLY_STORE 1      /* 128-column tile: two staging register sets, LDS stores ahead of the matrix phase (below) */
+#endif
+#ifndef DAVO_F32_EARLY_STORE_MIN_BN
+#define DAVO_F32_EARLY_STORE_MIN_BN 32      /* every tile but cnv1's 16-column one: measured on the narrow remainder tiles too (-2..4 %) */
+#endif
 #ifndef DAVO_F32_ABLATE_BARRIER
 #define DAVO_F32_ABLATE_BARRIER 0   /* timing experiments only */
 #endif
@@ -95,6 +101,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     // written float4 array in scratch and serialises every load behind a scratch store.
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // second set (EARLY_STORE below): chunk q + 2 is in flight while chunk q + 1 goes from the first set into LDS
+    float4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+    sa0 = sa1 = sa2 = sa3 = sb0 = sb1 = sb2 = sb3 = make_float4(0.f, 0.f, 0.f, 0.f);
     // Pixel addresses are carried from chunk to chunk: with Cin >= 32 a tap spans Cin / 32 consecutive chunks whose loads differ
     // by 32 channels (128 bytes) only, so the ~17 instructions per row of the bounds test and the 64-bit offset (several
     // quarter-rate integer multiplies) are paid on a tap's first chunk and the others add a step (0 for a row that reads the
@@ -112,7 +121,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         ptr_ = ok ? xg + off : p.zeros;                                                            \
         st_ = ok ? BK : 0;                                                                         \
     }
-#define DAVO_LOAD_CHUNK(q_)                                                                        \
+#define DAVO_LOAD_CHUNK(q_) DAVO_LOAD_CHUNK_R(q_, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
+#define DAVO_LOAD_CHUNK_R(q_, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)                              \
     {                                                                                              \
         const int kg = (q_) * BK + kk;                                                             \
         if (l_cb == 0) {                                                                           \
@@ -137,7 +147,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
             rb3 = *reinterpret_cast<const float4*>(wrow + 96L * p.Kpad);                           \
         }                                                                                          \
     }
-#define DAVO_STORE_CHUNK(buf_)                                                                     \
+#define DAVO_STORE_CHUNK(buf_) DAVO_STORE_CHUNK_R(buf_, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
+#define DAVO_STORE_CHUNK_R(buf_, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)                           \
     {                                                                                              \
         float* a_ = As + (buf_) * BM * LDK + r0 * LDK + kk;                                        \
         float* b_ = Bs + (buf_) * BN * LDK + r0 * LDK + kk;                                        \
@@ -232,6 +243,46 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         }                                                                                          \
     }
 
+    // EARLY_STORE (the 128-column tile, cnv4..cnv7's main launches): two sets of staging registers.  The loads of chunk q + 2 are issued
+    // at the top of chunk q, and chunk q + 1 - loaded a whole chunk ago - goes into the idle LDS buffer BEFORE chunk q's matrix phase
+    // instead of behind it: the eight LDS stores and their latency pass under the wave's own 64 MFMAs, and what is left between the last
+    // MFMA and the barrier is nothing.  (One set: loads at the top, matrix phase, then a staircase of vmcnt waits with the stores, an
+    // lgkmcnt(0), the barrier - ~500 cycles per chunk in which the SIMD only works if its other wave happens to be in ITS matrix
+    // phase.)  The idle buffer was last read in chunk q - 1, and every wave has passed the barrier behind that chunk.
+    constexpr bool EARLY_STORE = DAVO_F32_EARLY_STORE && BN >= DAVO_F32_EARLY_STORE_MIN_BN;
+    if constexpr (EARLY_STORE) {
+        int q = q0;
+        if (q + 1 < q1) DAVO_LOAD_CHUNK_R(q + 1, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3)        // chunk q0 + 1 -> second set
+#define DAVO_EARLY_STEP(buf_, RS_, RL_)                                                             \
+        {                                                                                          \
+            DAVO_STORE_CHUNK_R((buf_) ^ 1, RS_)                        /* chunk q + 1, landed long ago */ \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            if (q + 2 < q1) DAVO_LOAD_CHUNK_R(q + 2, RL_)              /* flies under this chunk and the next */ \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            DAVO_PRIO_UP(DAVO_MMPRIO);                                                             \
+            DAVO_COMPUTE(buf_)                                                                     \
+            DAVO_PRIO_DOWN(DAVO_MMPRIO);                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            if (!DAVO_F32_ABLATE_BARRIER) __syncthreads();                                         \
+            ++q;                                                                                   \
+        }
+#define DAVO_SET_S sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3
+#define DAVO_SET_R ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3
+        while (q + 2 < q1) {
+            DAVO_EARLY_STEP(0, DAVO_SET_S, DAVO_SET_R)
+            DAVO_EARLY_STEP(1, DAVO_SET_R, DAVO_SET_S)
+        }
+        // q + 2 >= q1 here and (q - q0) is even: one or two chunks are left
+        if (q + 1 < q1) {
+            DAVO_EARLY_STEP(0, DAVO_SET_S, DAVO_SET_R)
+            DAVO_COMPUTE(1)
+        } else {
+            DAVO_COMPUTE(0)
+        }
+#undef DAVO_EARLY_STEP
+#undef DAVO_SET_S
+#undef DAVO_SET_R
+    } else {
     for (int q = q0; q + 1 < q1; ++q) {
         const int buf = (q - q0) & 1;
         DAVO_LOAD_CHUNK(q + 1)                           // global loads fly under the MFMAs
@@ -244,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
         if (!DAVO_F32_ABLATE_BARRIER) __syncthreads();
     }
     DAVO_COMPUTE((q1 - 1 - q0) & 1)
+    }
 
     if constexpr (N16) {       // C/D layout of 16x16x4: col = lane & 15, row = 4 (lane >> 4) + r
         const int n = ntile * BN + l16;
@@ -324,6 +376,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
 
 #undef DAVO_ADDR_A
 #undef DAVO_LOAD_CHUNK
+#undef DAVO_LOAD_CHUNK_R
+#undef DAVO_STORE_CHUNK_R
 #undef DAVO_STORE_CHUNK
 #undef DAVO_COMPUTE
 #undef DAVO_COMPUTE16
