@@ -242,9 +242,12 @@ def main():
         achieved = flops_main / (avg6 * 1e-3) / 1e12 if avg6 > 0 else 0.0
         if precision == "f32":
             peak = PEAK_F32_MFMA_TFLOPS
-            kname = "davo::conv_igemm_f32<3,1,128,6> (cnv6 main launch: rotation|translation fused, N=256, K=2304)"
+            merged32 = len(plan) == 1 and H * W >= 128 * 416 and B >= 8
+            kname = ("davo::conv_igemm_f32_mainrem<3,1,64,6> (cnv6 whole layer, one launch: whole rounds of 128x128 tiles, then the remainder's "
+                     "128x64 tiles; rotation|translation fused, N=256, K=2304)" if merged32 else
+                     "davo::conv_igemm_f32<3,1,128,6> (cnv6 main launch: rotation|translation fused, N=256, K=2304)")
             peak_note = "FP32 MFMA dense peak (v_mfma_f32_32x32x2_f32)"
-            key = "conv_igemm_f32<3, 1, 128, 6>"
+            key = "conv_igemm_f32"
         else:
             # every algorithmic FLOP costs three fp16 MFMA FLOPs (hi*hi, hi*lo, lo*hi), so the
             # matrix-pipe roofline of this algorithm is the fp16 dense peak / 3
@@ -267,7 +270,8 @@ def main():
                 tj = json.load(open(f))
                 if tj.get("batch", 32) != B or (H, W) != (128, 416):
                     continue
-                hit = [v for k, v in tj["kernels"].items() if key in k and (precision == "f32" or "mainrem" in key or ", 6, true, false" in k)]
+                hit = [v for k, v in tj["kernels"].items() if key in k and ((precision == "f32" and k.rstrip().endswith(", 6>")) or
+                                                                              (precision != "f32" and ("mainrem" in key or ", 6, true, false" in k)))]
                 if hit:
                     hit.sort(key=lambda v: -(v["read_bytes"] + v["write_bytes"]))
                     traffic = hit[0]["read_bytes"] + hit[0]["write_bytes"]

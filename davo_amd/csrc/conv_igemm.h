@@ -55,7 +55,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // LAYER only names the instantiation (0 = generic, 1..7 = cnv1..cnv7) so that rocprofv3's
 // per-kernel statistics separate the layers that share a tile shape (cnv4/cnv5/cnv6).
 template <int KS, int STRIDE, int BN, int LAYER>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
+__device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const int wg_x, const int nwg_x, const int wg_y) {
     using T = Tile<BN>;
     constexpr bool N16 = BN == 16;             // 16 output columns: four waves of 32 x 16 on v_mfma_f32_16x16x4_f32
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -67,10 +67,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wid / T::WN, wn = wid % T::WN;
 
-    const int tile_i = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_i = xcd_remap(wg_x, nwg_x);
     const int tile = p.tile_order ? __builtin_amdgcn_readfirstlane(p.tile_order[tile_i]) : tile_i;
     const int ntile = tile % p.ntiles_n, mtile = p.mtile0 + tile / p.ntiles_n;
-    const int grp = blockIdx.y;
+    const int grp = wg_y;
     const float* __restrict__ xg = p.x + p.x_coff + grp * p.g_x_coff;
     const float* __restrict__ wg = p.w + grp * p.g_w + (long)ntile * BN * p.Kpad;
     const float* __restrict__ bg = p.bias + grp * p.g_bias + ntile * BN;
@@ -372,6 +372,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
                 if (n_ok && m < p.M) yg[(long)m * p.y_ld + n] = v;
             }
     }
+}
+
+template <int KS, int STRIDE, int BN, int LAYER>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
+    conv_igemm_f32_body<KS, STRIDE, BN, LAYER>(p, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// A layer's main launch (whole rounds of 128-column tiles) and its remainder launch (narrower tiles, forward.hip / plan.hip) as ONE
+// grid: the first n_main workgroups take the main tiles, the others the remainder's.  Workgroups are handed out strictly in id
+// order, so the remainder's tiles start on whichever CUs finish their last main tile first: the main launch's ragged tail (tiles
+// differ in length since the padding rows of the filter are skipped) and the remainder's start overlap instead of meeting at a
+// launch boundary.  Same tiles, same kernels' arithmetic: bit-identical to the two launches.  n_main is a multiple of 8, so a
+// remainder workgroup's ordinal keeps its id % 8 = its XCD.
+template <int KS, int STRIDE, int RBN, int LAYER>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32_mainrem(ConvParams pm, ConvParams pr, int n_main, int n_rem) {
+    if ((int)blockIdx.x < n_main) conv_igemm_f32_body<KS, STRIDE, 128, LAYER>(pm, blockIdx.x, n_main, blockIdx.y);
+    else conv_igemm_f32_body<KS, STRIDE, RBN, LAYER>(pr, blockIdx.x - n_main, n_rem, blockIdx.y);
 }
 
 #undef DAVO_ADDR_A

@@ -24,7 +24,32 @@ hipError_t launch_bn(int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+template <int KS, int STRIDE, int RBN, int LAYER>
+hipError_t launch_mainrem_t(const ConvParams& pm, const ConvParams& pr, int n_main, int n_rem, int groups, hipStream_t s) {
+    auto kern = conv_igemm_f32_mainrem<KS, STRIDE, RBN, LAYER>;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), Tile<128>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_main + n_rem, groups), dim3(256), Tile<128>::LDS_BYTES, s, pm, pr, n_main, n_rem);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+// main (128-column tiles) + remainder (rbn-column tiles) of cnv4..cnv7 as one grid (conv_igemm.h: conv_igemm_f32_mainrem)
+hipError_t launch_layer_mainrem(int layer, int rbn, const ConvParams& pm, const ConvParams& pr, int n_main, int n_rem, int groups, hipStream_t s) {
+    if (n_main < 8 || n_main % 8 || n_rem < 1) return hipErrorInvalidValue;
+    switch (layer * 1000 + rbn) {
+        case 3032: return launch_mainrem_t<3, 1, 32, 4>(pm, pr, n_main, n_rem, groups, s);
+        case 3064: return launch_mainrem_t<3, 1, 64, 4>(pm, pr, n_main, n_rem, groups, s);
+        case 4032: return launch_mainrem_t<3, 1, 32, 5>(pm, pr, n_main, n_rem, groups, s);
+        case 4064: return launch_mainrem_t<3, 1, 64, 5>(pm, pr, n_main, n_rem, groups, s);
+        case 5032: return launch_mainrem_t<3, 1, 32, 6>(pm, pr, n_main, n_rem, groups, s);
+        case 5064: return launch_mainrem_t<3, 1, 64, 6>(pm, pr, n_main, n_rem, groups, s);
+        case 6032: return launch_mainrem_t<3, 2, 32, 7>(pm, pr, n_main, n_rem, groups, s);
+        case 6064: return launch_mainrem_t<3, 2, 64, 7>(pm, pr, n_main, n_rem, groups, s);
+    }
+    return hipErrorInvalidValue;
+}
 
 hipError_t launch_conv(int KS, int stride, int BN, const ConvParams& p, dim3 grid, hipStream_t s) {
     if (stride == 1) {

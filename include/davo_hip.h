@@ -245,6 +245,10 @@ const char* davo_range_report(const davo_ctx* ctx);
  *       launch spreads over the whole chip, behind a ticket's memory-side round trip; kept for experiments.
  *   "f32_n16" (default 1; float32 mode): cnv1 (16 output channels) on a 128x16 tile with v_mfma_f32_16x16x4_f32 instead of the
  *       128x32 tile whose matrix instructions were half padding.  Another order of the same float32 fma chain per output.
+ *   "merge_rem_f32" (default 1; float32 mode): where cnv4 / cnv5 / cnv6 are planned as a main launch of whole rounds of 128-column tiles
+ *       plus a remainder launch of narrower ones, both run as ONE grid (csrc/conv_igemm.h, conv_igemm_f32_mainrem): workgroups are
+ *       handed out in id order, so the remainder's tiles start on the CUs that finish their last main tile first (float32 step
+ *       -1.8 % at B = 32; cnv7 measured slower merged and keeps two launches).  Bit-identical to 0.
  *   "patch_f32" (default 1; float32 mode): cnv1, cnv2 and cnv3 from an LDS-staged input patch on v_mfma_f32_16x16x4_f32
  *       (csrc/conv_patch_f32.h: the f16x3 patch kernels' recipe in float32) instead of the implicit GEMM: 0.153 / 0.070 / 0.091
  *       -> 0.108 / 0.049 / 0.069 ms at B = 32.  Another fixed order of the same float32 fma chain per output.
