@@ -32,6 +32,12 @@
 #ifndef DAVO_F32_EARLY_STORE
 #define DAVO_F32_EARLY_STORE 1      /* 128-column tile: two staging register sets, LDS stores ahead of the matrix phase (below) */
 #endif
+#ifndef DAVO_F32_FRAG0
+#define DAVO_F32_FRAG0 1            /* early-store loop: a chunk's first fragments are requested ahead of its LDS stores */
+#endif
+#ifndef DAVO_F32_FRAG_AHEAD
+#define DAVO_F32_FRAG_AHEAD 0       /* (experiment) group g + 1's fragments pinned ahead of group g's MFMAs with sched_barriers: +1.4 % SLOWER than the compiler's own interleaving */
+#endif
 #ifndef DAVO_F32_EARLY_STORE_MIN_BN
 #define DAVO_F32_EARLY_STORE_MIN_BN 32      /* every tile but cnv1's 16-column one: measured on the narrow remainder tiles too (-2..4 %) */
 #endif
@@ -243,6 +249,49 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
         }                                                                                          \
     }
 
+    // the same with the fragments of group 0 requested ahead (DAVO_FRAG0): the LDS serves its queue in order, so behind the eight stores
+    // of the early-store loop the first fragments of a chunk arrived ~100 cycles late; now they are requested first
+#define DAVO_FRAG0(buf_)                                                                           \
+    {                                                                                              \
+        const float* a = As + (buf_) * BM * LDK + (wm * T::TM * 32 + li) * LDK + 4 * lh;           \
+        const float* b = Bs + (buf_) * BN * LDK + (wn * T::TN * 32 + li) * LDK + 4 * lh;           \
+        _Pragma("unroll") for (int i = 0; i < T::TM; ++i) pf_a[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDK); \
+        _Pragma("unroll") for (int j = 0; j < T::TN; ++j) pf_b[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDK); \
+    }
+#define DAVO_COMPUTE_PF(buf_)                                                                      \
+    {                                                                                              \
+        const float* a = As + (buf_) * BM * LDK + (wm * T::TM * 32 + li) * LDK + 4 * lh;           \
+        const float* b = Bs + (buf_) * BN * LDK + (wn * T::TN * 32 + li) * LDK + 4 * lh;           \
+        float4 fa[2][T::TM], fb[2][T::TN];                                                         \
+        _Pragma("unroll") for (int i = 0; i < T::TM; ++i) fa[0][i] = pf_a[i];                      \
+        _Pragma("unroll") for (int j = 0; j < T::TN; ++j) fb[0][j] = pf_b[j];                      \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
+            /* group g + 1's fragments are requested before group g's MFMAs are queued (DAVO_F32_FRAG_AHEAD) */ \
+            if (DAVO_F32_FRAG_AHEAD && g + 1 < 4) {                                                \
+                _Pragma("unroll") for (int i = 0; i < T::TM; ++i)                                  \
+                    fa[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDK + (g + 1) * 8); \
+                _Pragma("unroll") for (int j = 0; j < T::TN; ++j)                                  \
+                    fb[(g + 1) & 1][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDK + (g + 1) * 8); \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+            }                                                                                      \
+            if (!DAVO_F32_FRAG_AHEAD && g > 0) {                                                   \
+                _Pragma("unroll") for (int i = 0; i < T::TM; ++i)                                  \
+                    fa[g & 1][i] = *reinterpret_cast<const float4*>(a + i * 32 * LDK + g * 8);     \
+                _Pragma("unroll") for (int j = 0; j < T::TN; ++j)                                  \
+                    fb[g & 1][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDK + g * 8);     \
+            }                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < T::TM; ++i)                                      \
+                _Pragma("unroll") for (int j = 0; j < T::TN; ++j) {                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].x, fb[g & 1][j].x, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].y, fb[g & 1][j].y, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].z, fb[g & 1][j].z, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].w, fb[g & 1][j].w, acc[i][j], 0, 0, 0); \
+                }                                                                                  \
+            if (DAVO_F32_FRAG_AHEAD) __builtin_amdgcn_sched_barrier(0);                            \
+        }                                                                                          \
+    }
+    float4 pf_a[T::TM], pf_b[T::TN];
+
     // EARLY_STORE (the 128-column tile, cnv4..cnv7's main launches): two sets of staging registers.  The loads of chunk q + 2 are issued
     // at the top of chunk q, and chunk q + 1 - loaded a whole chunk ago - goes into the idle LDS buffer BEFORE chunk q's matrix phase
     // instead of behind it: the eight LDS stores and their latency pass under the wave's own 64 MFMAs, and what is left between the last
@@ -255,12 +304,13 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
         if (q + 1 < q1) DAVO_LOAD_CHUNK_R(q + 1, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3)        // chunk q0 + 1 -> second set
 #define DAVO_EARLY_STEP(buf_, RS_, RL_)                                                             \
         {                                                                                          \
+            if (DAVO_F32_FRAG0) { DAVO_FRAG0(buf_) __builtin_amdgcn_sched_barrier(0); }            \
             DAVO_STORE_CHUNK_R((buf_) ^ 1, RS_)                        /* chunk q + 1, landed long ago */ \
             __builtin_amdgcn_sched_barrier(0);                                                     \
             if (q + 2 < q1) DAVO_LOAD_CHUNK_R(q + 2, RL_)              /* flies under this chunk and the next */ \
             __builtin_amdgcn_sched_barrier(0);                                                     \
             DAVO_PRIO_UP(DAVO_MMPRIO);                                                             \
-            DAVO_COMPUTE(buf_)                                                                     \
+            if (DAVO_F32_FRAG0) DAVO_COMPUTE_PF(buf_) else DAVO_COMPUTE(buf_)                      \
             DAVO_PRIO_DOWN(DAVO_MMPRIO);                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                     \
             if (!DAVO_F32_ABLATE_BARRIER) __syncthreads();                                         \
@@ -398,5 +448,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_mainrem(ConvParams pm, 
 #undef DAVO_STORE_CHUNK
 #undef DAVO_COMPUTE
 #undef DAVO_COMPUTE16
+#undef DAVO_FRAG0
+#undef DAVO_COMPUTE_PF
 
 }  // namespace davo
