@@ -258,14 +258,15 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
         _Pragma("unroll") for (int i = 0; i < T::TM; ++i) pf_a[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDK); \
         _Pragma("unroll") for (int j = 0; j < T::TN; ++j) pf_b[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDK); \
     }
-#define DAVO_COMPUTE_PF(buf_)                                                                      \
+#define DAVO_COMPUTE_PF(buf_) DAVO_COMPUTE_PF_G(buf_, 0, 4)
+#define DAVO_COMPUTE_PF_G(buf_, G0_, G1_)                                                           \
     {                                                                                              \
         const float* a = As + (buf_) * BM * LDK + (wm * T::TM * 32 + li) * LDK + 4 * lh;           \
         const float* b = Bs + (buf_) * BN * LDK + (wn * T::TN * 32 + li) * LDK + 4 * lh;           \
         float4 fa[2][T::TM], fb[2][T::TN];                                                         \
         _Pragma("unroll") for (int i = 0; i < T::TM; ++i) fa[0][i] = pf_a[i];                      \
         _Pragma("unroll") for (int j = 0; j < T::TN; ++j) fb[0][j] = pf_b[j];                      \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
+        _Pragma("unroll") for (int g = (G0_); g < (G1_); ++g) {                                    \
             /* group g + 1's fragments are requested before group g's MFMAs are queued (DAVO_F32_FRAG_AHEAD) */ \
             if (DAVO_F32_FRAG_AHEAD && g + 1 < 4) {                                                \
                 _Pragma("unroll") for (int i = 0; i < T::TM; ++i)                                  \
@@ -450,5 +451,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_mainrem(ConvParams pm, 
 #undef DAVO_COMPUTE16
 #undef DAVO_FRAG0
 #undef DAVO_COMPUTE_PF
+#undef DAVO_COMPUTE_PF_G
 
 }  // namespace davo
