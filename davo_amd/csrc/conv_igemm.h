@@ -458,12 +458,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
 // grid: the first n_main workgroups take the main tiles, the others the remainder's.  Workgroups are handed out strictly in id
 // order, so the remainder's tiles start on whichever CUs finish their last main tile first: the main launch's ragged tail (tiles
 // differ in length since the padding rows of the filter are skipped) and the remainder's start overlap instead of meeting at a
-// launch boundary.  Same tiles, same kernels' arithmetic: bit-identical to the two launches.  n_main is a multiple of 8, so a
-// remainder workgroup's ordinal keeps its id % 8 = its XCD.
+// launch boundary.  Same tiles, same kernels' arithmetic: bit-identical to the two launches.  n_main (and, for a grouped layer,
+// n_rem) is a multiple of 8, so a workgroup's ordinal keeps its id % 8 = its XCD.
+// A grouped layer (cnv7: two groups) keeps its groups in the x extent too - all main tiles of every group first, then all remainder
+// tiles: with the groups in grid.y, group 0's remainder ran in the middle of the grid.
 template <int KS, int STRIDE, int RBN, int LAYER>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32_mainrem(ConvParams pm, ConvParams pr, int n_main, int n_rem) {
-    if ((int)blockIdx.x < n_main) conv_igemm_f32_body<KS, STRIDE, 128, LAYER>(pm, blockIdx.x, n_main, blockIdx.y);
-    else conv_igemm_f32_body<KS, STRIDE, RBN, LAYER>(pr, blockIdx.x - n_main, n_rem, blockIdx.y);
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32_mainrem(ConvParams pm, ConvParams pr, int n_main, int n_rem, int groups) {
+    const int b = blockIdx.x, nm = groups * n_main;
+    if (b < nm) conv_igemm_f32_body<KS, STRIDE, 128, LAYER>(pm, b % n_main, n_main, b / n_main);
+    else conv_igemm_f32_body<KS, STRIDE, RBN, LAYER>(pr, (b - nm) % n_rem, n_rem, (b - nm) / n_rem);
 }
 
 #undef DAVO_ADDR_A

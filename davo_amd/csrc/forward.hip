@@ -198,12 +198,12 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
     // (cnv7 keeps its two launches: merged it measured 0.532 against 0.439 + 0.052 ms - its 32-column remainder tiles then run two per CU
     // on the main tile's LDS and register budget instead of three, and 0.545 with a 64-column remainder; cnv4 / cnv5 / cnv6: -5 / -4 / -1 %,
     // profiles/r05q_f32_mainrem_ab.md)
-    if (c->opt_merge_rem_f32 && li >= 3 && li <= 5 && plan.size() == 2 && plan[0].BN == 128 && (plan[1].BN == 32 || plan[1].BN == 64)) {
+    if (c->opt_merge_rem_f32 && li >= 3 && (li <= 5 || c->opt_merge_rem_f32 > 1) && plan.size() == 2 && plan[0].BN == 128 && (plan[1].BN == 32 || plan[1].BN == 64)) {
         ConvParams pm = p, pr = p;
         pm.mtile0 = plan[0].mtile0; pm.ntiles_n = L.npad / 128; pm.tile_order = order_for(plan[0], pm.ntiles_n);
         pr.mtile0 = plan[1].mtile0; pr.ntiles_n = L.npad / plan[1].BN; pr.tile_order = order_for(plan[1], pr.ntiles_n);
         const int n_main = plan[0].mtiles * pm.ntiles_n, n_rem = plan[1].mtiles * pr.ntiles_n;
-        if (n_main % 8 == 0) {
+        if (n_main % 8 == 0 && (L.groups == 1 || n_rem % 8 == 0)) {
             ProfScope ps(c, L.label);
             HIP_TRY(c, launch_layer_mainrem(li, plan[1].BN, pm, pr, n_main, n_rem, L.groups, c->stream));
             c->last_plan[li][0] = (plan[0].mtiles + plan[1].mtiles) * 1000 + 128;      // one launch covers the layer

@@ -29,7 +29,7 @@ hipError_t launch_mainrem_t(const ConvParams& pm, const ConvParams& pr, int n_ma
     auto kern = conv_igemm_f32_mainrem<KS, STRIDE, RBN, LAYER>;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), Tile<128>::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_main + n_rem, groups), dim3(256), Tile<128>::LDS_BYTES, s, pm, pr, n_main, n_rem);
+    hipLaunchKernelGGL(kern, dim3((n_main + n_rem) * groups), dim3(256), Tile<128>::LDS_BYTES, s, pm, pr, n_main, n_rem, groups);
     return hipGetLastError();
 }
 
@@ -37,7 +37,7 @@ hipError_t launch_mainrem_t(const ConvParams& pm, const ConvParams& pr, int n_ma
 
 // main (128-column tiles) + remainder (rbn-column tiles) of cnv4..cnv7 as one grid (conv_igemm.h: conv_igemm_f32_mainrem)
 hipError_t launch_layer_mainrem(int layer, int rbn, const ConvParams& pm, const ConvParams& pr, int n_main, int n_rem, int groups, hipStream_t s) {
-    if (n_main < 8 || n_main % 8 || n_rem < 1) return hipErrorInvalidValue;
+    if (n_main < 8 || n_main % 8 || n_rem < 1 || (groups > 1 && n_rem % 8)) return hipErrorInvalidValue;
     switch (layer * 1000 + rbn) {
         case 3032: return launch_mainrem_t<3, 1, 32, 4>(pm, pr, n_main, n_rem, groups, s);
         case 3064: return launch_mainrem_t<3, 1, 64, 4>(pm, pr, n_main, n_rem, groups, s);
