@@ -171,6 +171,7 @@ struct davo_ctx {
     int last_plan[7][2] = {};                  // per layer, per launch: 128-row M tiles * 1000 + tile id / BN (reported by the bench)
     // host-API staging
     void *s_img = nullptr, *s_flow = nullptr, *s_seg = nullptr, *s_pose = nullptr;
+    float* h_sync_pose = nullptr;              // davo_forward: page-locked bounce buffer of the poses
     hipStream_t copy_stream = nullptr;         // H2D of the next sub-batch runs here while the previous one computes
     std::vector<hipEvent_t> copy_done;
     // f16x3 range management: activations are stored as fp16 pairs scaled by 2^act_shift[layer] (davo_calibrate);
@@ -211,6 +212,7 @@ struct davo_ctx {
     float* d_reissue_pose = nullptr;           // a re-issued batch writes here first; copied to its own pose buffer unless a later batch has taken that
     std::deque<davo::PoseSpan> pose_spans;     // pose buffer ranges of the batches issued since the oldest pending ticket
     unsigned long long n_issued = 0;
+    int host_since_fresh = 1 << 30;            // davo_forward calls since the base record was last zeroed (api.hip); the first call starts afresh
     int since_fresh_record = 0;                // ticketed batches since one last started from a zeroed range record (api.hip: ticket_begin)
     // profiling
     bool prof = false;

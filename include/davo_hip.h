@@ -190,7 +190,9 @@ int davo_set_precision(davo_ctx* ctx, int precision);
 
 /* f16x3 range management.  Activations between layers are stored as fp16 (hi, lo) pairs; a layer's values must
  * stay below 65504 (they are clamped there) and its largest value above ~2^-11 for the pairs to carry float32-grade
- * precision.  Each storing kernel records the largest value it wrote; davo_forward checks the record of its own call.
+ * precision.  Each storing kernel records the largest value it wrote (running maxima: a clamped value is caught in the very call
+ * that stores it, "too small" on what has been stored since the record was last zeroed - by a recovery, a change of scales, and for
+ * every 256th call / batch); davo_forward judges the record at the end of its call.
  * The reference's float32 graph never fails on a finite network (davo.py:1553-1569), so by default neither does this
  * library: a batch that left the range is re-issued with the scales re-calibrated ON THAT BATCH, and if it still
  * leaves the range (no per-layer power of two covers it) on the float32 kernels — mode 0 below, for that batch only;

@@ -32,8 +32,13 @@ def main():
         return tuple(p[k:k + 1] for p in pinned)         # views of page-locked memory: no host copy per window
     eng = Engine(cfg, H, W, 1)
     eng.load_weights(synth.make_weights(cfg))
+    opts = [a for a in sys.argv[1:] if "=" in a]                      # e.g. fold_tails=1 fuse_pack=1 (davo_set_option)
+    sys.argv = [a for a in sys.argv if "=" not in a]
+    for kv in opts:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     eng.calibrate(*load(0, 1))
-    rec = {"what": "BASELINE configs[0] shape from memory: 799 windows, batch 1, 128x416, f16x3 (default arithmetic) and f32", "runs": []}
+    rec = {"what": "BASELINE configs[0] shape from memory: 799 windows, batch 1, 128x416, f16x3 (default arithmetic) and f32", "options": opts, "runs": []}
     ref = None
     for precision in ("f16x3", "f32"):
         eng.set_precision(precision)
