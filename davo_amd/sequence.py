@@ -133,10 +133,10 @@ class PoseStream:
     (test_kitti_pose.py:133-145, data_loader.py:321-324).  ``hold``: batches whose input arrays the source keeps valid after
     yielding the next one (0 for davo_amd.loader's loaders; arrays that are never recycled can take 8: no copy is waited for).
     ``inflight``: slots = streams the batches rotate through; a slot's stream runs copy -> kernels -> pose copy in order, so at
-    batch 1 (44 us of copy latency in front of 127 us of kernels) three slots keep the GPU busier than two: 8.7 k -> 10.5 k
-    windows/s on 799 windows (profiles/r05b_config1_b1.json)."""
+    batch 1 (44 us of copy latency in front of 127 us of kernels) more slots keep the GPU busier: 8.7 k windows/s with two, 10.5 k with
+    three, 12.3 k with four (the library's maximum) on 799 windows (profiles/r05b_config1_b1.json, r05z_b1_options.log)."""
 
-    def __init__(self, engine, inflight=3, hold=0):
+    def __init__(self, engine, inflight=4, hold=0):
         self.engine, self.hold = engine, hold
         engine.set_inflight(inflight)
 
