@@ -983,6 +983,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "split_k") c->opt_split_k = value != 0;
     else if (k == "fold_fixup") c->opt_fold_fixup = value != 0;
     else if (k == "f32_n16") c->opt_f32_n16 = value != 0;
+    else if (k == "f32_n256") c->opt_f32_n256 = value != 0;
     else if (k == "merge_rem_f32") c->opt_merge_rem_f32 = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (k == "patch_f32") c->opt_patch_f32 = value != 0;
     else if (k == "auto_range") { int rc = judge_all(c); if (rc) return rc; c->opt_auto_range = value != 0; }

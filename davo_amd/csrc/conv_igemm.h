@@ -87,10 +87,12 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
 
     // ---- staging assignment: thread -> (row r0+32j, 4 consecutive k at kk) ---------------
     const int r0 = tid >> 3, kk = (tid & 7) * 4;
+    constexpr int RPP = T::RPP;                // rows per staging pass: 32 (four waves) | 64 (eight)
     int iy0[4], ix0[4], pix0[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int m = mtile * BM + r0 + 32 * j;
+        if (j >= T::A_LOADS) { iy0[j] = -(1 << 28); ix0[j] = 0; pix0[j] = 0; continue; }
+        const int m = mtile * BM + r0 + RPP * j;
         if (m < p.M) {
             const int hw = p.Hout * p.Wout;
             const int n = m / hw, rem = m - n * hw;
@@ -139,21 +141,25 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
             const int ky = tap / KS, kx = tap - ky * KS;                                           \
             const int dy = ky * p.rate, dx = kx * p.rate;                                          \
             const bool tap_ok = tap < p.ntaps;                                                     \
-            DAVO_ADDR_A(0, pa0, st0) DAVO_ADDR_A(1, pa1, st1) DAVO_ADDR_A(2, pa2, st2) DAVO_ADDR_A(3, pa3, st3) \
+            DAVO_ADDR_A(0, pa0, st0) DAVO_ADDR_A(1, pa1, st1)                                      \
+            if constexpr (T::A_LOADS > 2) { DAVO_ADDR_A(2, pa2, st2) DAVO_ADDR_A(3, pa3, st3) }    \
         } else {                                                                                   \
-            pa0 += st0; pa1 += st1; pa2 += st2; pa3 += st3;                                        \
+            pa0 += st0; pa1 += st1;                                                                \
+            if constexpr (T::A_LOADS > 2) { pa2 += st2; pa3 += st3; }                              \
         }                                                                                          \
         l_cb = l_cb + 1 == cpt ? 0 : l_cb + 1;                                                     \
         ra0 = *reinterpret_cast<const float4*>(pa0);                                               \
         ra1 = *reinterpret_cast<const float4*>(pa1);                                               \
-        ra2 = *reinterpret_cast<const float4*>(pa2);                                               \
-        ra3 = *reinterpret_cast<const float4*>(pa3);                                               \
+        if constexpr (T::A_LOADS > 2) {                                                            \
+            ra2 = *reinterpret_cast<const float4*>(pa2);                                           \
+            ra3 = *reinterpret_cast<const float4*>(pa3);                                           \
+        }                                                                                          \
         const float* wrow = wg + (long)r0 * p.Kpad + (DAVO_F32_ABLATE_B ? kk : kg);               \
         if (!N16 || r0 < 16) rb0 = *reinterpret_cast<const float4*>(wrow);                         \
-        if constexpr (T::NB_LOADS > 1) rb1 = *reinterpret_cast<const float4*>(wrow + 32L * p.Kpad); \
+        if constexpr (T::NB_LOADS > 1) rb1 = *reinterpret_cast<const float4*>(wrow + (long)RPP * p.Kpad); \
         if constexpr (T::NB_LOADS > 2) {                                                           \
-            rb2 = *reinterpret_cast<const float4*>(wrow + 64L * p.Kpad);                           \
-            rb3 = *reinterpret_cast<const float4*>(wrow + 96L * p.Kpad);                           \
+            rb2 = *reinterpret_cast<const float4*>(wrow + 2L * RPP * p.Kpad);                      \
+            rb3 = *reinterpret_cast<const float4*>(wrow + 3L * RPP * p.Kpad);                      \
         }                                                                                          \
     }
 #define DAVO_STORE_CHUNK(buf_) DAVO_STORE_CHUNK_R(buf_, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
@@ -162,14 +168,16 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
         float* a_ = As + (buf_) * BM * LDK + r0 * LDK + kk;                                        \
         float* b_ = Bs + (buf_) * BN * LDK + r0 * LDK + kk;                                        \
         *reinterpret_cast<float4*>(a_) = ra0;                                                      \
-        *reinterpret_cast<float4*>(a_ + 32 * LDK) = ra1;                                           \
-        *reinterpret_cast<float4*>(a_ + 64 * LDK) = ra2;                                           \
-        *reinterpret_cast<float4*>(a_ + 96 * LDK) = ra3;                                           \
+        *reinterpret_cast<float4*>(a_ + RPP * LDK) = ra1;                                          \
+        if constexpr (T::A_LOADS > 2) {                                                            \
+            *reinterpret_cast<float4*>(a_ + 2 * RPP * LDK) = ra2;                                  \
+            *reinterpret_cast<float4*>(a_ + 3 * RPP * LDK) = ra3;                                  \
+        }                                                                                          \
         if (!N16 || r0 < 16) *reinterpret_cast<float4*>(b_) = rb0;                                 \
-        if constexpr (T::NB_LOADS > 1) *reinterpret_cast<float4*>(b_ + 32 * LDK) = rb1;            \
+        if constexpr (T::NB_LOADS > 1) *reinterpret_cast<float4*>(b_ + RPP * LDK) = rb1;           \
         if constexpr (T::NB_LOADS > 2) {                                                           \
-            *reinterpret_cast<float4*>(b_ + 64 * LDK) = rb2;                                       \
-            *reinterpret_cast<float4*>(b_ + 96 * LDK) = rb3;                                       \
+            *reinterpret_cast<float4*>(b_ + 2 * RPP * LDK) = rb2;                                  \
+            *reinterpret_cast<float4*>(b_ + 3 * RPP * LDK) = rb3;                                  \
         }                                                                                          \
     }
 
@@ -404,7 +412,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
             const int unit = tid / 6, k = tid - unit * 6;
             float t = 0.f;
             if (unit == 0)
-                for (int w = 0; w < 4; ++w) t += red[w * 6 + k];
+                for (int w = 0; w < T::WAVES; ++w) t += red[w * 6 + k];
             p.pose_partial[(((long)grp * p.pose_mt + mtile) * 8 + ntile * UNITS + unit) * 6 + k] = t;
         }
         return;
@@ -452,6 +460,13 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
 template <int KS, int STRIDE, int BN, int LAYER>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvParams p) {
     conv_igemm_f32_body<KS, STRIDE, BN, LAYER>(p, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// 128 x 256 tile, eight waves (64 x 64 each), one workgroup per CU (round 5 experiment, "f32_n256"): a pixel tile is staged once for
+// all 256 output channels of cnv5 / cnv6 instead of once per 128-column tile
+template <int KS, int STRIDE, int LAYER>
+__global__ __launch_bounds__(512, 1) void conv_igemm_f32_n256(ConvParams p) {
+    conv_igemm_f32_body<KS, STRIDE, 256, LAYER>(p, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // A layer's main launch (whole rounds of 128-column tiles) and its remainder launch (narrower tiles, forward.hip / plan.hip) as ONE

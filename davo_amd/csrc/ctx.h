@@ -127,6 +127,7 @@ struct davo_ctx {
     bool opt_tile_208x128 = false;             // f16x3: cnv4 may run on the four-wave 208x128 tile (conv_igemm_h3s.h; measured 8 % behind the 128x128 tile at B = 32: off)
     bool opt_merge_cnv4 = false;               // f16x3: cnv4 as whole rounds of 256x128 tiles + 128x128 remainder tiles in one grid where the batch allows
     bool opt_share_taps = true;                // f16x3: cnv3..cnv6 stage one pixel patch per filter row for its three taps
+    bool opt_f32_n256 = false;                 // f32 mode experiment: cnv5 / cnv6 on the 128 x 256 tile (eight waves, one workgroup per CU)
     int opt_merge_rem_f32 = 1;             // f32 mode: cnv4..cnv7 main + remainder launches as one grid (conv_igemm_f32_mainrem)
     bool opt_f32_n16 = true;                   // f32 mode: cnv1 (16 output channels) on the 128x16 tile / v_mfma_f32_16x16x4_f32 instead of the padded 128x32 one
     bool opt_fold_fixup = false;               // f16x3 split-K: the part that finishes a tile last adds its partial sums (no splitk_fixup launch); needs xcd_rr > 0.  Measured slower (batch 1: 0.141 against 0.132 ms): off

@@ -193,6 +193,29 @@ int run_conv_layer(davo_ctx* c, int li, const float* x, int x_ld, int Hin, int W
     auto order_for = [&](const Launch& l, int ntn) {
         return (L.KS == 3 && L.cin_log2 >= 5) ? tile_order_for(c, li, 0, BM, l.mtile0, l.mtiles, ntn, p.M, Ho, Wo, Hin, L.stride, pt, L.rate) : nullptr;
     };
+    // experiment ("f32_n256"): cnv5 / cnv6 as whole rounds of 128 x 256 tiles (eight waves, one workgroup per CU) + a remainder launch of
+    // 128 x 64 tiles
+    if (c->opt_f32_n256 && (li == 4 || li == 5) && L.npad == 256 && L.groups == 1 && !fuse_pose && mtiles >= c->ncu) {
+        const int main_m = (mtiles / c->ncu) * c->ncu;
+        ConvParams pm = p;
+        pm.mtile0 = 0; pm.ntiles_n = 1;
+        pm.tile_order = tile_order_for(c, li, 2, BM, 0, main_m, 1, p.M, Ho, Wo, Hin, L.stride, pt, L.rate);
+        {
+            ProfScope ps(c, L.label);
+            HIP_TRY(c, launch_layer_n256(li, pm, dim3(main_m, 1), c->stream));
+        }
+        c->last_plan[li][0] = main_m * 1000 + 256;
+        if (main_m < mtiles) {
+            ConvParams pr = p;
+            pr.mtile0 = main_m; pr.ntiles_n = L.npad / 64;
+            pr.tile_order = tile_order_for(c, li, 0, BM, main_m, mtiles - main_m, pr.ntiles_n, p.M, Ho, Wo, Hin, L.stride, pt, L.rate);
+            const std::string label = std::string(L.label) + ".rem";
+            ProfScope ps(c, label.c_str());
+            HIP_TRY(c, launch_layer(li, 64, pr, dim3((mtiles - main_m) * pr.ntiles_n, 1), c->stream));
+            c->last_plan[li][1] = (mtiles - main_m) * 1000 + 64;
+        }
+        return DAVO_OK;
+    }
     // main + remainder as one grid (conv_igemm.h, conv_igemm_f32_mainrem; "merge_rem_f32"): the remainder's tiles start on the CUs
     // that finish their last main tile first, instead of behind a launch boundary.  Same tiles, same arithmetic.
     // (cnv7 keeps its two launches: merged it measured 0.532 against 0.439 + 0.052 ms - its 32-column remainder tiles then run two per CU

@@ -19,6 +19,7 @@ hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
 hipError_t launch_conv(int KS, int stride, int BN, const ConvParams& p, dim3 grid, hipStream_t s);
 // the seven PoseNN layers (layer 0..6 = cnv1..cnv7), each under its own kernel name; BN is chosen per launch
 hipError_t launch_layer(int layer, int BN, const ConvParams& p, dim3 grid, hipStream_t s);
+hipError_t launch_layer_n256(int layer, const ConvParams& p, dim3 grid, hipStream_t s);
 hipError_t launch_layer_mainrem(int layer, int rbn, const ConvParams& pm, const ConvParams& pr, int n_main, int n_rem, int groups, hipStream_t s);
 
 // ---- launch_h3.hip: conv_igemm_h3 (f16x3) -----------------------------------------------------------

@@ -33,7 +33,23 @@ hipError_t launch_mainrem_t(const ConvParams& pm, const ConvParams& pr, int n_ma
     return hipGetLastError();
 }
 
+template <int LAYER>
+hipError_t launch_n256_t(const ConvParams& p, dim3 grid, hipStream_t s) {
+    auto kern = conv_igemm_f32_n256<3, 1, LAYER>;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), Tile<256>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(512), Tile<256>::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+// cnv5 / cnv6 on the 128 x 256 tile (eight waves): experiment, "f32_n256"
+hipError_t launch_layer_n256(int layer, const ConvParams& p, dim3 grid, hipStream_t s) {
+    if (layer == 4) return launch_n256_t<5>(p, grid, s);
+    if (layer == 5) return launch_n256_t<6>(p, grid, s);
+    return hipErrorInvalidValue;
+}
 
 // main (128-column tiles) + remainder (rbn-column tiles) of cnv4..cnv7 as one grid (conv_igemm.h: conv_igemm_f32_mainrem)
 hipError_t launch_layer_mainrem(int layer, int rbn, const ConvParams& pm, const ConvParams& pr, int n_main, int n_rem, int groups, hipStream_t s) {

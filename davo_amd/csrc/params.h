@@ -93,15 +93,18 @@ constexpr int LDK = 36;          // padded LDS row (floats)
 // 32 rows x 16 columns on v_mfma_f32_16x16x4_f32 (conv_igemm.h).
 template <int BN> struct Tile;
 template <> struct Tile<16> {
-    static constexpr int WN = 1, WM = 4, TM = 1, TN = 1, NB_LOADS = 1;
+    static constexpr int WN = 1, WM = 4, TM = 1, TN = 1, NB_LOADS = 1, WAVES = 4, RPP = 32, A_LOADS = 4;
     static constexpr int LDS_BYTES = 2 * (128 + 16) * 36 * 4;
 };
 template <int BN> struct Tile {
-    static constexpr int WN = BN >= 64 ? 2 : 1;    // waves along N
-    static constexpr int WM = 4 / WN;              // waves along M
+    static constexpr int WAVES = BN == 256 ? 8 : 4;    // 256 columns (round 5 experiment): eight waves, one workgroup per CU
+    static constexpr int WN = BN == 256 ? 4 : (BN >= 64 ? 2 : 1);    // waves along N
+    static constexpr int WM = WAVES / WN;          // waves along M
     static constexpr int TM = BM / WM / 32;        // 32x32 MFMA tiles per wave along M
     static constexpr int TN = BN / WN / 32;
-    static constexpr int NB_LOADS = BN / 32;       // float4 weight loads per thread per chunk
+    static constexpr int RPP = WAVES * 8;          // tile rows one staging pass of the workgroup covers (a thread: 4 floats of one row)
+    static constexpr int A_LOADS = BM / RPP;       // float4 pixel loads per thread per chunk (4 | 2)
+    static constexpr int NB_LOADS = BN / RPP;      // float4 weight loads per thread per chunk
     static constexpr int LDS_BYTES = 2 * (BM + BN) * LDK * 4;
 };
 

@@ -247,6 +247,9 @@ const char* davo_range_report(const davo_ctx* ctx);
  *       launch spreads over the whole chip, behind a ticket's memory-side round trip; kept for experiments.
  *   "f32_n16" (default 1; float32 mode): cnv1 (16 output channels) on a 128x16 tile with v_mfma_f32_16x16x4_f32 instead of the
  *       128x32 tile whose matrix instructions were half padding.  Another order of the same float32 fma chain per output.
+ *   "f32_n256" (default 0; float32 mode): cnv5 / cnv6 on a 128 x 256 tile of eight waves, one workgroup per CU (csrc/conv_igemm.h,
+ *       conv_igemm_f32_n256): a pixel tile is staged once for all 256 output channels.  Bit-identical; measured 4 % slower per step
+ *       than the 128-column tiles (eight waves behind one barrier stay in step: MEASURED_AND_REJECTED.md); kept for experiments.
  *   "merge_rem_f32" (default 1; float32 mode): where cnv4 / cnv5 / cnv6 are planned as a main launch of whole rounds of 128-column tiles
  *       plus a remainder launch of narrower ones, both run as ONE grid (csrc/conv_igemm.h, conv_igemm_f32_mainrem): workgroups are
  *       handed out in id order, so the remainder's tiles start on the CUs that finish their last main tile first (float32 step
