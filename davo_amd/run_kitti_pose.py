@@ -72,7 +72,7 @@ def main(argv=None):
     ap.add_argument("--report", default=None, help="write the run's time split (load wait / forward / gather / stitch / write) as JSON here")
     ap.add_argument("--sync_driver", action="store_true",
                     help="one synchronous davo_forward per batch (input wait + copy + kernels + pose copy add up) instead of the streaming "
-                         "entry point (davo_submit: four batches in flight, copies and input wait overlapped with the kernels)")
+                         "entry point (davo_submit: three batches in flight (four up to batch 2), copies and input wait overlapped with the kernels)")
     a = ap.parse_args(argv)
     # start-up split (wall clock).  Only the first main() of a process can say what the process start cost
     global _FIRST_MAIN

@@ -133,11 +133,15 @@ class PoseStream:
     (test_kitti_pose.py:133-145, data_loader.py:321-324).  ``hold``: batches whose input arrays the source keeps valid after
     yielding the next one (0 for davo_amd.loader's loaders; arrays that are never recycled can take 8: no copy is waited for).
     ``inflight``: slots = streams the batches rotate through; a slot's stream runs copy -> kernels -> pose copy in order, so at
-    batch 1 (44 us of copy latency in front of 127 us of kernels) more slots keep the GPU busier: 8.7 k windows/s with two, 10.5 k with
-    three, 12.3 k with four (the library's maximum) on 799 windows (profiles/r05b_config1_b1.json, r05z_b1_options.log)."""
+    batch 1 (44 us of copy latency in front of 127 us of kernels) more slots keep the GPU busier: 8.8 k windows/s with two, 10.6 k with
+    three, 12.4 k with four (the library's maximum) on 799 windows; at batch 32 three are best (f16x3 from page-locked host memory:
+    14.7 k / 23.1 k / 26.7 k / 22.6 k triplets/s with one to four slots - four forwards of 3,000-workgroup launches at once break up
+    the launch plan's whole rounds; float32 8.9 k from two slots on = the HBM-resident rate).  Default: four up to batch 2, else three."""
 
-    def __init__(self, engine, inflight=4, hold=0):
+    def __init__(self, engine, inflight=None, hold=0):
         self.engine, self.hold = engine, hold
+        if inflight is None:            # measured: profiles/r05ac_config1_b1.json (batch 1), profiles/r05af_host_api.log (batch 32)
+            inflight = 4 if engine.max_batch <= 2 else 3
         engine.set_inflight(inflight)
 
     def submit(self, img, flow, seg, out):

@@ -59,7 +59,7 @@ def main():
         assert len(open(os.path.join(d, "00-pred_kitti_pose.txt")).read().splitlines()) == N
     rec = {"what": "BASELINE configs[3] shape on ONE rank from files (seq 00: 4541 frames, 4539 windows, batch 64, forced RCCL gather); "
                    "8 ranks would each take 568 of these windows" + (": THIS run is the work of rank %s" % shard if shard else ""),
-           "driver": "synchronous (davo_forward per batch)" if sync else "streamed (davo_submit, four batches in flight)",
+           "driver": "synchronous (davo_forward per batch)" if sync else "streamed (davo_submit, three batches in flight (four up to batch 2))",
            "fresh_process_per_run": fresh, "images": images, "mean_jpeg_bytes_per_strip": jpg_bytes, "runs": runs}
     print(json.dumps(rec, indent=1))
     if out:

@@ -35,3 +35,27 @@ for label, bufs in (("pageable", (img, flow, seg)), ("pinned", pinned)):
         dt = time.perf_counter() - t0
         print("davo_forward host buffers %-8s host_chunk=%d: %8.1f triplets/s, %.3f ms per batch of %d, %.1f MB H2D per batch -> %.1f GB/s"
               % (label, chunk, B * n / dt, dt / n * 1e3, B, mb, mb * n / dt / 1e3), flush=True)
+
+# round 5: the streaming entry point on the same batch (davo_submit, four slots; pinned arrays held for the whole run: hold = 8)
+for prec in ("f16x3", "f32"):
+    e.set_precision(prec)
+    outs = [np.empty((B, 2, 6), np.float32) for _ in range(n)]
+    for slots in (1, 2, 3, 4):
+        e.set_inflight(slots)
+        for rep in range(2):
+            t0 = time.perf_counter()
+            for o in outs:
+                e.submit(*pinned, o, hold=8)
+            e.synchronize()
+            dt = time.perf_counter() - t0
+        print("davo_submit   host buffers pinned   %-5s %d slot(s)    : %8.1f triplets/s, %.3f ms per batch of %d (PCIe-inclusive)"
+              % (prec, slots, B * n / dt, dt / n * 1e3, B), flush=True)
+    e.set_inflight(1)
+    e.set_option("host_chunk", 8)
+    e.forward(*pinned)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        e.forward(*pinned)
+    dt = time.perf_counter() - t0
+    print("davo_forward  host buffers pinned   %-5s host_chunk=8 : %8.1f triplets/s, %.3f ms per batch of %d (PCIe-inclusive)"
+          % (prec, B * n / dt, dt / n * 1e3, B), flush=True)
