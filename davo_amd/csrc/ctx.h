@@ -149,7 +149,8 @@ struct davo_ctx {
     std::string err;
     std::map<std::string, davo::HostTensor> weights;
     std::vector<std::string> needed;
-    bool packed_ready = false;
+    bool packed_ready = false;                 // float32 convolution weights packed (built at the first float32 forward)
+    bool pred_ready = false;                   // pose head kernels on the device (every mode)
     davo::ConvLayer L[7];                      // cnv1..cnv5, cnv6 (fused), cnv7 (grouped)
     float *d_wpred = nullptr, *d_bpred = nullptr;
     uint8_t* d_w1patch = nullptr;              // cnv1 B fragments for conv_patch_cnv1_h3
@@ -279,6 +280,7 @@ std::vector<std::string> needed_names(const Variant& v);
 bool expected_shape(const davo_ctx* c, const std::string& name, std::vector<int64_t>* sh);
 int upload(davo_ctx* c, const std::vector<float>& host, float** dev);
 int build_packed_weights(davo_ctx* c);
+int build_pred_weights(davo_ctx* c);
 int build_packed_weights_h3(davo_ctx* c);
 int missing_weights(davo_ctx* c, std::string* names);
 float weight_prescale(const float* w, size_t n);

@@ -547,6 +547,10 @@ int run_direct(davo_ctx* c, const char* label, const float* x, int N, int Hin, i
     int Ho, Wo, pt, pl;
     same_pad(Hin, KS, stride, rate, &Ho, &pt);
     same_pad(Win, KS, stride, rate, &Wo, &pl);
+    for (const std::string* n : {&wname, &bname}) {            // impl 1 is the only reader of the raw device copies: made on demand
+        HostTensor& t = c->weights.at(*n);
+        if (!t.dev) { int rc = upload(c, t.data, &t.dev); if (rc) return rc; }
+    }
     ProfScope ps(c, label);
     HIP_TRY(c, launch_conv_direct(x, N, Hin, Win, cin, x_ld, x_coff, c->weights.at(wname).dev, KS, cout,
                                   c->weights.at(bname).dev, stride, rate, pt, pl, Ho, Wo, 1, y, y_ld, y_coff, c->stream));
@@ -563,7 +567,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
         if (missing_weights(c, &names)) return fail(c, DAVO_ERR_NOT_READY, "weights not loaded: %s", names.c_str());
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->packed_ready) { int rc = build_packed_weights(c); if (rc) return rc; }
+    if (!c->pred_ready) { int rc = build_pred_weights(c); if (rc) return rc; }
     bool h3 = c->impl == 0 && c->precision == 1;
     c->f32_fallback = false;
     if (h3 && !c->packed_h_ready) { int rc = build_packed_weights_h3(c); if (rc) return rc; }
@@ -581,6 +585,7 @@ int forward_device(davo_ctx* c, int B, const void* d_img, const void* d_flow, co
                  c->weight_channel_spread_layer.c_str(), c->weight_channel_spread_log2, MAX_WEIGHT_CHANNEL_SPREAD_LOG2);
         c->range_report = note;
     }
+    if (!h3 && c->impl == 0 && !c->packed_ready) { int rc = build_packed_weights(c); if (rc) return rc; }      // float32 kernels: packed at their first use
     unsigned* const range_reset = (h3 && c->range_zero) ? c->d_range : nullptr;
 
     const int H = c->H, W = c->W, HW = H * W, NB = 2 * B;

@@ -151,6 +151,24 @@ void init_layer(ConvLayer& L, const char* label, int KS, int stride, int rate, i
     L.npad_h = (cout + gran - 1) / gran * gran;
 }
 
+// the pose head's 1x1 kernels [2][256][3] + [2][3]: every arithmetic mode reads them, so they are built at the first forward whatever
+// the mode; the float32 convolution weights (below) only when a float32 forward is issued (round 5: a rank that runs f16x3 packs
+// and uploads 13 MB less in front of its first batch)
+int build_pred_weights(davo_ctx* c) {
+    auto W = [&](const std::string& n) -> const HostTensor& { return c->weights.at(n); };
+    const char* heads[2] = {"rotation", "translation"};
+    std::vector<float> wp(2 * 256 * 3), bp(2 * 3);
+    for (int h = 0; h < 2; ++h) {
+        const std::string p = std::string("pose_exp_net/pose/") + heads[h] + "/pred/";
+        memcpy(wp.data() + h * 768, W(p + "weights").data.data(), 768 * sizeof(float));
+        memcpy(bp.data() + h * 3, W(p + "biases").data.data(), 3 * sizeof(float));
+    }
+    int rc = upload(c, wp, &c->d_wpred); if (rc) return rc;
+    rc = upload(c, bp, &c->d_bpred); if (rc) return rc;
+    c->pred_ready = true;
+    return DAVO_OK;
+}
+
 int build_packed_weights(davo_ctx* c) {
     const int c6 = c->v.cnv6_out, cpf = c->v.cin_per_frame;
     auto W = [&](const std::string& n) -> const HostTensor& { return c->weights.at(n); };

@@ -34,12 +34,13 @@ _FIRST_MAIN = True
 
 
 def _process_start_time():
-    """wall-clock time this process was created (the kernel's record: /proc/self/stat field 22 against the boot time)"""
+    """wall-clock time this process was created: its age from /proc (start time in clock ticks since boot against the uptime, 10 ms
+    resolution - btime in /proc/stat is whole seconds and put up to a second of error into round 5's first start-up splits)"""
     try:
         ticks = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[19])
-        btime = next(int(ln.split()[1]) for ln in open("/proc/stat") if ln.startswith("btime"))
-        return btime + ticks / os.sysconf("SC_CLK_TCK")
-    except (OSError, ValueError, StopIteration):
+        uptime = float(open("/proc/uptime").read().split()[0])
+        return time.time() - (uptime - ticks / os.sysconf("SC_CLK_TCK"))
+    except (OSError, ValueError, IndexError):
         return None
 
 

@@ -3,7 +3,7 @@
 reference's on-disk format -> CLI (worker-process loader, RCCL all-gather forced at world size 1) -> trajectory, with the run's
 time split.  The dump holds 640 distinct windows; the rest are links to them (same files, same decode work, warm page cache).
 
-    python tools/config4_from_files.py [out.json] [--shard r/R] [--images noise|scene] [--sync] [--fresh]
+    python tools/config4_from_files.py [out.json] [--shard r/R] [--images noise|scene] [--sync] [--fresh] [--no-comm]
         --shard 3/8: only what rank 3 of 8 would do (568 windows); --sync: the synchronous driver (one davo_forward per batch)
         instead of the streaming entry point; --fresh: every run is a process of its own (`python -m davo_amd.run_kitti_pose`),
         so the report's start-up split (process start -> first batch) is a rank's real one"""
@@ -33,7 +33,8 @@ def main():
         argv.remove("--images")
     sync = "--sync" in argv
     fresh = "--fresh" in argv
-    argv = [a for a in argv if a not in ("--sync", "--fresh")]
+    no_comm = "--no-comm" in argv          # one GPU, no RCCL communicator (the start-up split without librccl)
+    argv = [a for a in argv if a not in ("--sync", "--fresh", "--no-comm")]
     out = argv[0] if argv else None
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         L.write_synthetic_dump(d, 0, real, H, W, images=images)
@@ -46,7 +47,7 @@ def main():
         for rep in range(3):                                           # run 0 pays the library's first load and the cold page cache
             t0 = time.perf_counter()
             cli = (["--concat_img_dir", d, "--ckpt_file", os.path.join(d, "w.npz"), "--output_dir", d, "--test_seq", "0",
-                    "--batch_size", str(B), "--force_comm", "--report", os.path.join(d, "report.json")] +
+                    "--batch_size", str(B), "--report", os.path.join(d, "report.json")] + ([] if no_comm else ["--force_comm"]) +
                    (["--emulate_shard", shard] if shard else []) + (["--loader_procs", procs] if procs else []) + (["--sync_driver"] if sync else []))
             if fresh:
                 import subprocess
@@ -60,7 +61,7 @@ def main():
     rec = {"what": "BASELINE configs[3] shape on ONE rank from files (seq 00: 4541 frames, 4539 windows, batch 64, forced RCCL gather); "
                    "8 ranks would each take 568 of these windows" + (": THIS run is the work of rank %s" % shard if shard else ""),
            "driver": "synchronous (davo_forward per batch)" if sync else "streamed (davo_submit, three batches in flight (four up to batch 2))",
-           "fresh_process_per_run": fresh, "images": images, "mean_jpeg_bytes_per_strip": jpg_bytes, "runs": runs}
+           "fresh_process_per_run": fresh, "rccl_communicator": not no_comm, "images": images, "mean_jpeg_bytes_per_strip": jpg_bytes, "runs": runs}
     print(json.dumps(rec, indent=1))
     if out:
         json.dump(rec, open(out, "w"), indent=1)
