@@ -404,10 +404,6 @@ class ProcessWindowLoader:
                      np.ndarray((B, 4, H, W, 2), np.float32, buffer=trio[1].buf),
                      np.ndarray((B, 3, H, W, 1), np.float32, buffer=trio[2].buf))
             self._views.append(views)
-            if self.pin is not None:
-                for v in views:
-                    self.pin(v)
-                    self._pinned.append(v)
         self._ctrl_shm = shared_memory.SharedMemory(create=True, size=8 * (2 + 2 * P))
         self._ctrl = np.ndarray((2 + 2 * P,), np.int64, buffer=self._ctrl_shm.buf)
         self._ctrl[:] = 0
@@ -420,6 +416,29 @@ class ProcessWindowLoader:
                                         self.chunk, self.nring, self._sem, self._errq)) for k in range(P)]
         for p in self._pool:                              # forks of the warm server: they attach the buffers and start filling at once
             p.start()
+        # Page-locking (hipHostRegister) allocates and pins every page: 0.3 s for the 1.4 GB of a batch-64 ring, which used to sit in
+        # front of a rank's first batch.  It runs on a thread of its own now, ring entry by ring entry, behind the workers' start; the
+        # consumer waits only for the entry of the batch it is about to hand out.
+        self._pin_ready = [threading.Event() for _ in self._views]
+        self._pin_thread = None
+        if self.pin is not None:
+            def pin_all():
+                try:
+                    for i, views in enumerate(self._views):
+                        for v in views:
+                            self.pin(v)
+                            self._pinned.append(v)
+                        self._pin_ready[i].set()
+                except BaseException as exc:               # noqa: BLE001 - re-raised by the consumer
+                    self._pin_exc = exc
+                    for ev in self._pin_ready:
+                        ev.set()
+            self._pin_exc = None
+            self._pin_thread = threading.Thread(target=pin_all, name="davo-loader-pin", daemon=True)
+            self._pin_thread.start()
+        else:
+            for ev in self._pin_ready:
+                ev.set()
         # what batch bi needs: per worker, the number of its chunks among the chunks of batches 0..bi (its chunks run in order)
         self._cpb = -(-B // self.chunk)
         self._need = np.zeros(P, np.int64)
@@ -452,6 +471,10 @@ class ProcessWindowLoader:
         a shared-memory mapping alive).  Called by __del__; iteration itself only stops the workers (_stop)."""
         self._stop()
         self._started = False
+        t = getattr(self, "_pin_thread", None)
+        if t is not None:
+            t.join()
+            self._pin_thread = None
         if self.unpin is not None:
             for v in self._pinned:
                 try:
@@ -508,6 +531,9 @@ class ProcessWindowLoader:
                 # asking for batch bi releases the batches up to bi - 1 - hold: their ring entries may be refilled
                 self._ctrl[0] = max(0, bi - self.hold) + self.nring
                 self._wait_for(bi)
+                self._pin_ready[bi % self.nring].wait()
+                if getattr(self, "_pin_exc", None) is not None:
+                    raise self._pin_exc
                 s = self.lo + bi * self.B
                 e = min(s + self.B, self.hi)
                 yield s, e, tuple(v[:e - s] for v in self._views[bi % self.nring])

@@ -71,6 +71,9 @@ def main(argv=None):
     ap.add_argument("--emulate_shard", default=None, metavar="r/R",
                     help="measurement aid: do what rank r of R would do (its window shard, the gather, the whole stitch) in this one process")
     ap.add_argument("--report", default=None, help="write the run's time split (load wait / forward / gather / stitch / write) as JSON here")
+    ap.add_argument("--calibrate_on_first_windows", action="store_true",
+                    help="calibrate every rank on windows 0..7 of the sequence (loaded inline) instead of on its own first batch: the storage "
+                         "scales, and so the trajectory's last bits, then do not depend on the number of GPUs")
     ap.add_argument("--sync_driver", action="store_true",
                     help="one synchronous davo_forward per batch (input wait + copy + kernels + pose copy add up) instead of the streaming "
                          "entry point (davo_submit: three batches in flight (four up to batch 2), copies and input wait overlapped with the kernels)")
@@ -103,27 +106,15 @@ def main(argv=None):
         preload_in_background()
     import threading
     loader_thread = None
+    gpu_ready = threading.Event()
     H, W = a.img_height, a.img_width
-    # the GPU context first: the communicator's thread needs it, and HIP's own initialisation (0.3-0.4 s) is on every path
-    from . import _lib
-    _lib.lib()
-    mark("library_loaded")
-    system = DAVO(version=a.version, device=device_index)
-    system.setup_inference(H, W, "davo", a.seq_length, a.batch_size)
-    mark("gpu_context_created")
-    # the communicator is not needed before the gather: the id exchange and ncclCommInitRank (1.5-1.7 s, most of it inside HIP's
-    # code-object loading, which other HIP calls queue behind) run on a second thread from here on (collective; fails loudly at the
-    # gather, no other transport)
-    comm = RcclComm.from_env_async(system.engine) if need_comm else None
-
+    load = weights = None
     if a.synthetic:
-        from . import synth
         n_frames = a.synthetic
-        load = S.synthetic_window_loader(H, W)
-        weights = synth.make_weights(a.version)
     else:
         if a.loader_procs != 0:
-            # the fork server the loader's workers come from starts importing numpy / Pillow now (davo_amd/loader.py: worker_context)
+            # the fork server the loader's workers come from starts importing numpy / Pillow now (davo_amd/loader.py: worker_context);
+            # it is a spawned interpreter that never touches a GPU, and its 0.2 s of imports pass behind HIP's initialisation
             from .loader import warm_workers
             warm_workers()
         d = os.path.join(a.concat_img_dir, "%.2d" % a.test_seq)
@@ -144,27 +135,64 @@ def main(argv=None):
         load = S.kitti_window_loader(a.concat_img_dir, a.test_seq, n_frames, H, W,
                                      alloc=lambda shape, dtype: pinned_empty(shape, dtype, device_index),
                                      workers=a.loader_threads, decode_procs=a.decode_procs, procs=procs,
-                                     pin=lambda arr: pin_array(arr, device_index), unpin=unpin_array,
+                                     pin=lambda arr: (gpu_ready.wait(), pin_array(arr, device_index)), unpin=unpin_array,
                                      seg_planes=(0, 1, 2) if static_all else None, hold=0 if a.sync_driver else 1)
-        # the loader's buffers are created and page-locked (1.4 GB at batch 64: 0.2-0.3 s) and its workers start filling them on a
-        # thread of its own while the checkpoint is read and packed for the GPU
+        # the loader's buffers are created and its workers start filling them on a thread of its own, before anything else: the
+        # workers need no GPU.  Page-locking the buffers (1.4 GB at batch 64: 0.3 s) follows on the loader's own thread, entry by
+        # entry, once the context below exists: HIP serialises hipHostRegister with the context's own allocations, and pinning
+        # beside them made the context 0.25 s slower (profiles/r05an_config4_scene_shard_nocomm.json against r05ao).
         shard = S.shard_windows(n_frames - 2, *((world, rank) if emulate is None else (emulate[1], emulate[0])))
         loader_thread = threading.Thread(target=load.prestart, args=(shard[0], shard[1], a.batch_size), name="davo-loader-start")
         loader_thread.start()
+    # the GPU context: the communicator's thread needs it, and HIP's own initialisation (0.2-0.4 s) is on every path
+    from . import _lib
+    try:
+        _lib.lib()
+        mark("library_loaded")
+        system = DAVO(version=a.version, device=device_index)
+        system.setup_inference(H, W, "davo", a.seq_length, a.batch_size)
+        mark("gpu_context_created")
+    finally:
+        gpu_ready.set()                        # also on failure: the loader's pinning thread must not wait for ever
+    # the communicator is not needed before the gather: the id exchange and ncclCommInitRank (1.5-1.7 s, most of it inside HIP's
+    # code-object loading, which other HIP calls queue behind) run on a second thread from here on (collective; fails loudly at the
+    # gather, no other transport)
+    comm = RcclComm.from_env_async(system.engine) if need_comm else None
+
+    if a.synthetic:
+        from . import synth
+        load = S.synthetic_window_loader(H, W)
+        weights = synth.make_weights(a.version)
+    else:
         from .tf_checkpoint import load_weights
         weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
     mark("inputs_and_weights_ready")
     system.load_weights(weights)
     mark("weights_on_gpu")
     infer = lambda img, flow, seg: system.inference(None, "pose", inputs=(img, flow, seg))["pose"]   # noqa: E731
-    if not a.no_calibrate:
-        # every rank calibrates on the same first windows, so the trajectory does not depend on the world size.  Eight windows at
-        # most: the scales are powers of two with 64x headroom, and loading them inline is in front of the first batch
-        system.calibrate(load(0, min(a.batch_size, 8, n_frames - 2)))
-    mark("calibrated_first_forward_done")
     if loader_thread is not None:
         loader_thread.join()
     mark("loader_started")
+    lo_hi = S.shard_windows(n_frames - 2, *((world, rank) if emulate is None else (emulate[1], emulate[0])))
+    ld = load.for_range(*lo_hi, a.batch_size) if hasattr(load, "for_range") else load
+    batches = ld
+    if not a.no_calibrate:
+        if a.calibrate_on_first_windows or a.synthetic or not hasattr(ld, "__iter__") or lo_hi[0] >= lo_hi[1]:
+            # windows 0..7 of the sequence on every rank: the storage scales - and with them the trajectory's last bits - do not
+            # depend on the world size.  Loaded inline: Pillow's import and eight decodes in front of this rank's first batch
+            system.calibrate(load(0, min(a.batch_size, 8, n_frames - 2)))
+        else:
+            # the first eight windows of THIS rank's first batch, which its loader's workers are decoding anyway (round 5: the inline
+            # load was 0.35 s of a rank's 0.8 s start-up, most of it importing Pillow into this process).  The scales are exact
+            # powers of two with 64x headroom: ranks that calibrate on different windows agree to float32 rounding
+            # (test_calibration_is_neutral_for_a_well_ranged_checkpoint), not to the bit: --calibrate_on_first_windows restores that
+            import itertools
+            it = iter(ld)
+            first = next(it)
+            n8 = min(8, first[1] - first[0])
+            system.calibrate(tuple(x[:n8] for x in first[2]))
+            batches = itertools.chain([first], it)
+    mark("calibrated_first_forward_done")
     # streamed: a batch of the process loader stays valid while the next one is asked for (hold = 1), so davo_submit does not wait for
     # its own copy; the threaded loader and the synthetic windows give no such promise (hold = 0)
     from .loader import ProcessWindowLoader
@@ -173,10 +201,8 @@ def main(argv=None):
     timing = {}
     # this rank's prefetching loader (started above): handed in ready-made and closed only after the trajectory is written -
     # unpinning and unmapping ~1 GB of batch buffers takes 0.15 s and used to run inside run_sequence when the last reference died
-    lo_hi = S.shard_windows(n_frames - 2, *((world, rank) if emulate is None else (emulate[1], emulate[0])))
-    ld = load.for_range(*lo_hi, a.batch_size) if hasattr(load, "for_range") else load
     stream = None if a.sync_driver else S.PoseStream(system.engine, hold=stream_hold(ld))
-    traj, poses = S.run_sequence(infer, ld, n_frames, a.batch_size, rank, world, comm, timing, emulate, stream)
+    traj, poses = S.run_sequence(infer, batches, n_frames, a.batch_size, rank, world, comm, timing, emulate, stream)
     dt = time.perf_counter() - t0
     if rank == 0:
         os.makedirs(a.output_dir, exist_ok=True)
