@@ -144,6 +144,17 @@ def main(argv=None):
         shard = S.shard_windows(n_frames - 2, *((world, rank) if emulate is None else (emulate[1], emulate[0])))
         loader_thread = threading.Thread(target=load.prestart, args=(shard[0], shard[1], a.batch_size), name="davo-loader-start")
         loader_thread.start()
+        # ... and the checkpoint is read and parsed (0.06-0.1 s of file and numpy work, no GPU) on a third
+        from .tf_checkpoint import load_weights
+        ckpt = {}
+
+        def read_checkpoint():
+            try:
+                ckpt["weights"] = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
+            except BaseException as exc:                           # noqa: BLE001 - re-raised by the main thread below
+                ckpt["error"] = exc
+        weights_thread = threading.Thread(target=read_checkpoint, name="davo-checkpoint-read")
+        weights_thread.start()
     # the GPU context: the communicator's thread needs it, and HIP's own initialisation (0.2-0.4 s) is on every path
     from . import _lib
     try:
@@ -164,8 +175,10 @@ def main(argv=None):
         load = S.synthetic_window_loader(H, W)
         weights = synth.make_weights(a.version)
     else:
-        from .tf_checkpoint import load_weights
-        weights = load_weights(a.ckpt_file)        # TF V2 checkpoint (prefix / .index / directory) or .npz
+        weights_thread.join()
+        if "error" in ckpt:
+            raise ckpt["error"]
+        weights = ckpt["weights"]
     mark("inputs_and_weights_ready")
     system.load_weights(weights)
     mark("weights_on_gpu")
