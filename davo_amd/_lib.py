@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 # translation units of the library (csrc/ctx.h lists what each one holds); built in parallel, linked into one .so
-UNITS = ("api", "forward", "plan", "weights", "launch_f32", "launch_h3", "launch_h3s", "launch_h3_generic", "launch_misc", "comm")
+UNITS = ("api", "forward", "plan", "weights", "launch_f32", "launch_h3", "launch_h3s", "launch_h3w", "launch_h3_generic", "launch_misc", "comm")
 
 
 # -fno-slp-vectorize: with SLP vectorisation hipcc (ROCm 7.2) fuses neighbouring scalar float updates into packed

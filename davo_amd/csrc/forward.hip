@@ -328,7 +328,10 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         const int n_main = plan[0].rows / 256, n_rem = ((plan[1].rows + 127) / 128) * rem_ntn;
         // the shape test comes first: a profiling scope is opened only around a launch that is really issued
         // (an empty event pair under the layer's label would halve its average and advance the stride counter twice)
-        if (layer_h3_mainrem_supported(li, pm, n_main, n_rem)) {
+        // "wave128": the four-wave main tile (conv_igemm_h3w.h) runs as a launch of its own - merged with four-wave remainder tiles it
+        // measured 0.262 / 0.497 ms for cnv5 / cnv6 against 0.258 / 0.487 as two launches (profiles/r05bc_w128_ab.log)
+        const bool own_launch = c->opt_wave128 && merge_256 && layer_h3w_supported(li, pm);
+        if (!own_launch && layer_h3_mainrem_supported(li, pm, n_main, n_rem)) {
             // f16x3: long-first measured 256.8 against 259.9 us on cnv5 with a third more HBM reads (205 -> 272 MB: neighbours no longer
             // run side by side) and no change of the power-capped step: natural order unless "skip_order" is 2
             pm.tile_order = c->opt_skip_order >= 2 ? tile_order_for(c, li, 1, 256, 0, n_main, 1, pm.M, Ho, Wo, Hin, L.stride, pt, L.rate) : nullptr;
@@ -411,7 +414,10 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         const std::string label = i == 0 ? std::string(L.label) : std::string(L.label) + ".rem";
         {
             ProfScope ps(c, label.c_str());
-            HIP_TRY(c, launch_layer_h3(li, plan[i].tile, p, grid, c->stream));
+            if (c->opt_wave128 && plan[i].tile == TILE_256x256 && L.groups == 1 && !fuse_pose && layer_h3w_supported(li, p))
+                HIP_TRY(c, launch_layer_h3w(li, p, grid, c->stream));
+            else
+                HIP_TRY(c, launch_layer_h3(li, plan[i].tile, p, grid, c->stream));
         }
         p.M = full_m;
     }

@@ -32,6 +32,9 @@ bool layer_h3_mainrem_supported(int layer, const ConvParamsH& pm, int n_main, in
 hipError_t launch_layer_h3_mainrem(int layer, const ConvParamsH& pm, int n_main, const ConvParamsH& pr, int n_rem, int order, hipStream_t s);
 // launch_h3s.hip: conv_igemm_h3s (TILE_208x256) for layer 4..6 = cnv5, cnv6, cnv7
 hipError_t launch_layer_h3s(int layer, const ConvParamsH& p, dim3 grid, hipStream_t s);
+// conv_igemm_h3w.h: 256x256 tiles on four waves of 128x128 (cnv5, cnv6; option "wave128")
+bool layer_h3w_supported(int layer, const ConvParamsH& p);
+hipError_t launch_layer_h3w(int layer, const ConvParamsH& p, dim3 grid, hipStream_t s);
 hipError_t launch_h3_generic(int KS, int stride, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s);
 
 // ---- launch_misc.hip: prologue, pose head, cnv1 patch kernel, direct convolution ---------------------
