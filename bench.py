@@ -255,12 +255,16 @@ def main():
             tiles = {0: "128x32", 1: "256x64", 2: "256x128", 3: "128x256", 4: "128x128", 5: "256x256", 6: "208x256",
                      7: "256x256 + 128x128 remainder tiles in one grid"}
             merged = plan[0][1] == 7
+            # round 5: launches of whole 256x256 tiles run on conv_igemm_h3w (four waves of 128x128 outputs) unless "wave128" is 0
+            wave128 = plan[0][1] == 5 and "wave128=0" not in (getattr(args, "options", "") or "").replace(" ", "")
             kname = ("davo::%s (cnv6 %s: rotation|translation fused, N=256, K=2304, %s tile, LDS-DMA staged, "
-                     "v_mfma_f32_16x16x32_f16)" % ("conv_igemm_h3_mainrem<6,2>" if merged else "conv_igemm_h3<3,1,...,6,true,false,true>",
-                                                   "whole layer, one launch" if merged else "main launch", tiles.get(plan[0][1], "?")))
+                     "v_mfma_f32_16x16x32_f16)" % ("conv_igemm_h3_mainrem<6,2>" if merged else
+                                                   ("conv_igemm_h3w<6,2>" if wave128 else "conv_igemm_h3<3,1,...,6,true,false,true>"),
+                                                   "whole layer, one launch" if merged else "main launch",
+                                                   tiles.get(plan[0][1], "?") + (" on four waves of 128x128 outputs" if wave128 else "")))
             peak_note = ("fp16 MFMA dense peak 2500 TFLOP/s / 3 products per algorithmic FLOP.  What loops of nothing but this matrix "
                          "instruction sustain under the board power cap is measured in profiles/r04d_mfma_peak_probe{,2}.log and DESIGN.md section 2")
-            key = "conv_igemm_h3_mainrem<6" if merged else "conv_igemm_h3<3, 1, "
+            key = "conv_igemm_h3_mainrem<6" if merged else ("conv_igemm_h3w<6" if wave128 else "conv_igemm_h3<3, 1, ")
         # HBM traffic of the dominant kernel: from the most recent committed PMC pass (profiles/), not live —
         # rocprofv3 counter collection cannot run inside the timed process
         traffic, traffic_src, busy = None, None, None
@@ -271,7 +275,7 @@ def main():
                 if tj.get("batch", 32) != B or (H, W) != (128, 416):
                     continue
                 hit = [v for k, v in tj["kernels"].items() if key in k and ((precision == "f32" and k.rstrip().endswith(", 6>")) or
-                                                                              (precision != "f32" and ("mainrem" in key or ", 6, true, false" in k)))]
+                                                                              (precision != "f32" and ("mainrem" in key or "h3w<" in key or ", 6, true, false" in k)))]
                 if hit:
                     hit.sort(key=lambda v: -(v["read_bytes"] + v["write_bytes"]))
                     traffic = hit[0]["read_bytes"] + hit[0]["write_bytes"]
