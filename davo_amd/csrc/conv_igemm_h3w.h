@@ -341,6 +341,292 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_h3w(ConvParamsH p) {
     conv_igemm_h3w_body<LAYER, RATE>(p, blockIdx.x, gridDim.x);
 }
 
+
+// ---- the layer's remainder rows: 256 x 64 tiles (conv_igemm_h3w64) ------------------------------------------------------------
+// At B = 32 cnv5 / cnv6 are 3.25 rounds of 256-row tiles; the last quarter round ran as 256 workgroups of conv_igemm_h3's 128x128 tile
+// (three ring slots): 33 / 57 us for 7.7 % of the rows, MFMA busy 0.26 / 0.38 - a chain of 72 chunks at 0.79 us each, which is what a CU
+// takes in from L2 (32 KB per chunk at ~45 GB/s), not what its matrix pipe needs (0.32 us).  Same rows, same 256 workgroups, less to
+// stage: a 256-row x 64-channel tile stages the shared pixel patch (11 KB per chunk's share) and 8 KB of weights per chunk - 19 KB for the
+// same 3.1 MFLOP.  Four waves of 64 x 64 outputs (wave w = rows 64 w ..), conv_igemm_h3w's slots and barrier placement; a chunk is only
+// 48 matrix instructions per wave (0.32 us), so the rings are deep: weights four chunks ahead in a ring of six, patches two super-chunks
+// ahead in a ring of three, and the wait in front of the barrier is COUNTED (everything but the DMA of the newest three chunks).
+template <int RATE> struct TileW64 {
+    static constexpr int PR = TileW<RATE>::PR, PATCH = PR * 128, BSLOT = 64 * 128, NB = 6, NP = 3, AHEAD = 4;
+    static constexpr int LDS_BYTES = NP * PATCH + NB * BSLOT + 4 * 1024 + 128;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS per workgroup");
+};
+
+#define W64_WAIT4(n_, a_) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a_[0]), "+v"(a_[1]), "+v"(a_[2]), "+v"(a_[3]) : "n"(n_))
+#define W64_PASS(a_, b_, J_) { W_MFMA1(a_, b_, 0, J_); W_MFMA1(a_, b_, 1, J_); W_MFMA1(a_, b_, 2, J_); W_MFMA1(a_, b_, 3, J_); }
+#define W64_PASS4(a_, b_, J_, S0_, S1_, S2_, S3_) \
+    W_SLOT(a_, b_, 0, J_, S0_) W_SLOT(a_, b_, 1, J_, S1_) W_SLOT(a_, b_, 2, J_, S2_) W_SLOT(a_, b_, 3, J_, S3_)
+// patch slot (always issued: a slot past the patch's end reads outside the tensor into the wave's parking KB, so that every wave's
+// vmcnt counts the same five DMA instructions per chunk)
+#define W64_XC(t_, j_, abuf_)                                                                      \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (w_lds_t*)(((j_) < 8 || (8 * wave_u + (j_) * 32) < PR)                     \
+                                                     ? As + (abuf_) * TW::PATCH + ((j_) * 32 + 8 * wave_u) * 128 : xdummy + wave_u * 1024), \
+                                             16, ((j_) < 8 || (8 * wave_u + (j_) * 32) < PR) ? xvo##t_ : 0xFFFFFF00u, 0, 0, 0)
+#define W64_BDMA(j_, slot_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (w_lds_t*)(Bs + (slot_) * TW::BSLOT + ((j_) * 32 + 8 * wave_u) * 128), 16, boff[j_], wsoff, 0, 0)
+#define W64_BODY(KX_, CUR_)                                                                        \
+    {                                                                                              \
+        constexpr int NKX_ = ((KX_) + 1) % 3;                                                      \
+        const unsigned b0_ = lds_u32(Bs + wslot * TW::BSLOT + l16 * 128);                          \
+        const unsigned b_h = b0_ + foff16[0], b_l = b0_ + foff16[1];                               \
+        /* weights of chunk q + 4 = tap (KX_ + 1) % 3 of the next super-chunk (the one after it for KX_ = 2) -> ring slot wslot + 4 */ \
+        const unsigned wsoff = ((KX_) == 2 ? w2 : w1) + NKX_ * 128;                                \
+        const int wdst = wslot + 4 >= TW::NB ? wslot + 4 - TW::NB : wslot + 4;                     \
+        /* ---- column group 0 */                                                                  \
+        W_RD(bh[2], b_h, 2 * 2048); W_RD(bl[2], b_l, 2 * 2048);                                    \
+        W64_WAIT4(9, AH[CUR_]); W_WAIT1(9, bh[0]);                                                 \
+        W64_PASS(AH[CUR_], bh[0], 0)                                                               \
+        W_SB;                                                                                      \
+        W_WAIT1(8, bl[0]);                                                                         \
+        W64_PASS(AH[CUR_], bl[0], 0)                                                               \
+        W_SB;                                                                                      \
+        W64_WAIT4(4, AL[CUR_]);                                                                    \
+        W64_PASS(AL[CUR_], bh[0], 0)                                                               \
+        W_SB;                                                                                      \
+        /* ---- column group 1: the chunk's five DMA instructions */                               \
+        W_RD(bh[3], b_h, 3 * 2048); W_RD(bl[3], b_l, 3 * 2048);                                    \
+        W_WAIT2(4, bh[1], bl[1]);                                                                  \
+        W64_PASS4(AH[CUR_], bh[1], 1, W_XA(0, (KX_) * 3 + 0), W_XB(0, (KX_) * 3 + 0), W64_XC(0, (KX_) * 3 + 0, pbuf2), W_XA(1, (KX_) * 3 + 1)) \
+        W64_PASS4(AH[CUR_], bl[1], 1, W_XB(1, (KX_) * 3 + 1), W64_XC(1, (KX_) * 3 + 1, pbuf2), W_XA(2, (KX_) * 3 + 2), W_XB(2, (KX_) * 3 + 2)) \
+        W64_PASS4(AL[CUR_], bh[1], 1, W64_XC(2, (KX_) * 3 + 2, pbuf2), W64_BDMA(0, wdst), W64_BDMA(1, wdst), W_NOP)                        \
+        W_SB;                                                                                      \
+        /* ---- column group 2 */                                                                  \
+        W_WAIT2(2, bh[2], bl[2]);                                                                  \
+        W64_PASS(AH[CUR_], bh[2], 2) W64_PASS(AH[CUR_], bl[2], 2) W64_PASS(AL[CUR_], bh[2], 2)     \
+        W_SB;                                                                                      \
+        W_WAIT2(0, bh[3], bl[3]);                                                                  \
+        /* ---- column group 3: everything but the DMA of the newest three chunks has landed (the next chunk's weights were issued three    \
+           chunks ago, the next super-chunk's patch during the super-chunk before this one) */     \
+        {                                                                                          \
+            __builtin_amdgcn_s_waitcnt((15 & 15) | (7 << 4) | (15 << 8) | ((15 >> 4) << 14));      /* vmcnt(15) */ \
+            __builtin_amdgcn_s_barrier();                                                          \
+            const unsigned pb_ = lds_u32(As + ((KX_) == 2 ? pbuf1 : pbuf0) * TW::PATCH);           \
+            const int nrow_ = xrow0 + NKX_ * RATE;                                                 \
+            const unsigned na_h = pb_ + (unsigned)(nrow_ * 128 + ((q16 ^ (nrow_ & 6)) * 16));      \
+            const unsigned na_l = pb_ + (unsigned)(nrow_ * 128 + (((4 + q16) ^ (nrow_ & 6)) * 16)); \
+            const int nws_ = wslot + 1 == TW::NB ? 0 : wslot + 1;                                  \
+            const unsigned nb0_ = lds_u32(Bs + nws_ * TW::BSLOT + l16 * 128);                      \
+            const unsigned nb_h = nb0_ + foff16[0], nb_l = nb0_ + foff16[1];                       \
+            W_SB;                                                                                  \
+            W64_PASS4(AH[CUR_], bh[3], 3, W_XRD(AH[(CUR_) ^ 1][0], 0, na_h, NKX_), W_XRD(AH[(CUR_) ^ 1][1], 1, na_h, NKX_),               \
+                      W_XRD(AH[(CUR_) ^ 1][2], 2, na_h, NKX_), W_XRD(AH[(CUR_) ^ 1][3], 3, na_h, NKX_))                                    \
+            W64_PASS4(AH[CUR_], bl[3], 3, W_RD(bh[0], nb_h, 0), W_RD(bl[0], nb_l, 0),               \
+                      W_XRD(AL[(CUR_) ^ 1][0], 0, na_l, NKX_), W_XRD(AL[(CUR_) ^ 1][1], 1, na_l, NKX_))                                    \
+            W64_PASS4(AL[CUR_], bh[3], 3, W_XRD(AL[(CUR_) ^ 1][2], 2, na_l, NKX_), W_XRD(AL[(CUR_) ^ 1][3], 3, na_l, NKX_),               \
+                      W_RD(bh[1], nb_h, 2048), W_RD(bl[1], nb_l, 2048))                            \
+        }                                                                                          \
+        W_SB;                                                                                      \
+        wslot = wslot + 1 == TW::NB ? 0 : wslot + 1;                                               \
+    }
+
+template <int LAYER, int RATE>
+__global__ __launch_bounds__(256, 1) void conv_igemm_h3w64(ConvParamsH p) {
+    using TW = TileW64<RATE>;
+    constexpr int PR = TW::PR;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_w6[];
+    uint8_t* As = smem_w6;                              // [3][PR][128] pixel patches
+    uint8_t* Bs = smem_w6 + TW::NP * TW::PATCH;         // [6][64][128] weight ring
+    uint8_t* xdummy = Bs + TW::NB * TW::BSLOT;          // 1 KB per wave: where a patch slot past the patch's end lands
+    const unsigned xzero = lds_u32(xdummy + 4 * 1024);  // 128 zero bytes (what a tap reads outside its image row)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, q16 = lane >> 4;
+    if (tid < 8) *reinterpret_cast<float4*>(xdummy + 4 * 1024 + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = tile & 3, mtile = p.mtile0 + (tile >> 2);          // four N tiles of 64 channels per 256-row tile
+    const uint8_t* __restrict__ xg = p.x + p.x_boff;
+    const uint8_t* __restrict__ wg = p.w + (long)ntile * 64 * p.w_row_bytes;
+    int ky0, nky;
+    {
+        const FilterRows fr = valid_filter_rows(mtile * 256, mtile * 256 + 255, p.Hout, p.Wout, p.Hin, 1, p.pad_t, p.rate);
+        ky0 = __builtin_amdgcn_readfirstlane(fr.ky0);
+        nky = __builtin_amdgcn_readfirstlane(fr.nky);
+    }
+    const int nsc = (p.nchunks / 9) * nky;
+
+    const int r0 = tid >> 3;
+    unsigned boff[2];
+    {
+        const int u = (tid & 7) ^ ((r0 >> 1) & 7);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) boff[j] = (unsigned)((r0 + 32 * j) * (int)p.w_row_bytes + u * 16);
+    }
+    const int ux = (tid & 7) ^ (r0 & 6);
+    unsigned poff[9];
+    int xyv[9];
+    {
+        const int hw = p.Hout * p.Wout;
+        const unsigned uoff = (unsigned)((ux >> 2) * 64 + (ux & 3) * 16);
+        const int q32 = 32 / p.Wout, r32 = 32 - q32 * p.Wout;
+        int n = 0, y = 0, x = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int row = r0 + 32 * j;
+            const int f = mtile * 256 - RATE + row;
+            const bool ok = row < PR && f >= 0 && f < p.Mtot;
+            if (j < 2) {
+                const int fc = f >= 0 ? f : 0;
+                n = fc / hw;
+                const int rem = fc - n * hw;
+                y = rem / p.Wout;
+                x = rem - y * p.Wout;
+            } else {
+                x += r32; y += q32;
+                if (x >= p.Wout) { x -= p.Wout; ++y; }
+                if (y >= p.Hout) { y -= p.Hout; ++n; }
+            }
+            poff[j] = ((unsigned)((n * p.Hin + y - RATE) * p.Win + x) << p.x_pix_log2) + uoff;
+            xyv[j] = ok ? y - RATE : -(1 << 28);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(xg), 0, (int)((unsigned)p.Mtot << p.x_pix_log2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wg), 0, (int)(64u * (unsigned)p.w_row_bytes), 0x00020000);
+    const int xrow0 = wave_u * 64 + l16;
+    unsigned xkeep = 0;
+    {
+        int x = (mtile * 256 + xrow0) % p.Wout;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (x >= RATE) xkeep |= 1u << i;
+            if (x < p.Wout - RATE) xkeep |= 1u << (8 + i);
+            x += 16;
+            if (x >= p.Wout) x -= p.Wout;
+        }
+    }
+    int foff16[2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) foff16[pl] = ((pl * 4 + q16) ^ ((l16 >> 1) & 7)) * 16;
+
+    f32x4 acc[4][4];
+    {
+        const float inv = p.bias_scale;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float bv = p.bias[ntile * 64 + j * 16 + l16] * inv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = bv;
+        }
+    }
+    half8 AH[2][4], AL[2][4], bh[4], bl[4];
+
+    // (channel block, filter row) of a super-chunk; super-chunks past the end repeat the last one (their DMA is never read)
+    auto sc_coords = [&](int s, int& cblk, int& ky) {
+        const int sv = s < nsc ? s : nsc - 1;
+        cblk = sv / nky;
+        ky = ky0 + (sv - cblk * nky);
+    };
+    auto w_at = [](int cb, int ky) { return (unsigned)((cb * 3 + ky) * 3) * 128u; };      // byte offset of its first weight chunk
+    auto w_of = [&](int s) { int cb, ky; sc_coords(s, cb, ky); return w_at(cb, ky); };
+
+    // ---- prologue: patches of super-chunks 0 and 1, weights of chunks 0..3; then the first chunk's first fragments
+#define W64_PROLOGUE_PATCH(S_, BUF_)                                                               \
+    {                                                                                              \
+        int cb_, ky_; sc_coords(S_, cb_, ky_);                                                     \
+        const int xdy = (S_) < nsc ? ky_ * RATE : -(1 << 28);                                      \
+        const unsigned xsoff = ((unsigned)(ky_ * RATE * p.Win) << p.x_pix_log2) + (unsigned)cb_ * 128u;      \
+        W_XA(0, 0); W_XB(0, 0); W64_XC(0, 0, BUF_); W_XA(1, 1); W_XB(1, 1); W64_XC(1, 1, BUF_); W_XA(2, 2); W_XB(2, 2); W64_XC(2, 2, BUF_); \
+        W_XA(3, 3); W_XB(3, 3); W64_XC(3, 3, BUF_); W_XA(4, 4); W_XB(4, 4); W64_XC(4, 4, BUF_); W_XA(5, 5); W_XB(5, 5); W64_XC(5, 5, BUF_); \
+        W_XA(6, 6); W_XB(6, 6); W64_XC(6, 6, BUF_); W_XA(7, 7); W_XB(7, 7); W64_XC(7, 7, BUF_); W_XA(8, 8); W_XB(8, 8); W64_XC(8, 8, BUF_); \
+    }
+    W64_PROLOGUE_PATCH(0, 0)
+    W64_PROLOGUE_PATCH(1, 1)
+#undef W64_PROLOGUE_PATCH
+    {
+        const unsigned wa = w_of(0), wb = w_of(1);
+        { const unsigned wsoff = wa; W64_BDMA(0, 0); W64_BDMA(1, 0); }
+        { const unsigned wsoff = wa + 128; W64_BDMA(0, 1); W64_BDMA(1, 1); }
+        { const unsigned wsoff = wa + 256; W64_BDMA(0, 2); W64_BDMA(1, 2); }
+        { const unsigned wsoff = wb; W64_BDMA(0, 3); W64_BDMA(1, 3); }
+    }
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));             // vmcnt(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the zero row's ds_write
+    __builtin_amdgcn_s_barrier();
+    {
+        const unsigned pb_ = lds_u32(As);
+        const unsigned na_h = pb_ + (unsigned)(xrow0 * 128 + ((q16 ^ (xrow0 & 6)) * 16));
+        const unsigned na_l = pb_ + (unsigned)(xrow0 * 128 + (((4 + q16) ^ (xrow0 & 6)) * 16));
+        const unsigned nb0_ = lds_u32(Bs + l16 * 128);
+        W_XRD(AH[0][0], 0, na_h, 0) W_XRD(AH[0][1], 1, na_h, 0) W_XRD(AH[0][2], 2, na_h, 0) W_XRD(AH[0][3], 3, na_h, 0)
+        W_RD(bh[0], nb0_ + foff16[0], 0); W_RD(bl[0], nb0_ + foff16[1], 0);
+        W_XRD(AL[0][0], 0, na_l, 0) W_XRD(AL[0][1], 1, na_l, 0) W_XRD(AL[0][2], 2, na_l, 0) W_XRD(AL[0][3], 3, na_l, 0)
+        W_RD(bh[1], nb0_ + foff16[0], 2048); W_RD(bl[1], nb0_ + foff16[1], 2048);
+    }
+    W_SB;
+
+    // ---- main loop: chunk q = 3 sc + kx alternates between the two fragment sets, so two super-chunks are unrolled
+    int wslot = 0;                                        // ring slot of the current chunk's weights
+    int pbuf0 = 0, pbuf1 = 1, pbuf2 = 2;                  // patch buffers of super-chunks sc, sc + 1, sc + 2
+    // coordinates of super-chunks sc + 1 and sc + 2, walked without divisions
+    int cb1, ky1, cb2, ky2;
+    sc_coords(1, cb1, ky1);
+    sc_coords(2, cb2, ky2);
+#define W64_SUPER(P0_, P1_, P2_)                                                                   \
+    {                                                                                              \
+        const int xdy = sc + 2 < nsc ? ky2 * RATE : -(1 << 28);      /* the super-chunk whose patch this one fetches */ \
+        const unsigned xsoff = ((unsigned)(ky2 * RATE * p.Win) << p.x_pix_log2) + (unsigned)cb2 * 128u;       \
+        const unsigned w1 = w_at(cb1, ky1), w2 = w_at(cb2, ky2);                                   \
+        W64_BODY(0, P0_) W64_BODY(1, P1_) W64_BODY(2, P2_)                                         \
+        { const int t_ = pbuf0; pbuf0 = pbuf1; pbuf1 = pbuf2; pbuf2 = t_; }                        \
+        cb1 = cb2; ky1 = ky2;                                                                      \
+        if (sc + 3 < nsc) { if (++ky2 == ky0 + nky) { ky2 = ky0; ++cb2; } }                        \
+        ++sc;                                                                                      \
+    }
+    int sc = 0;
+    while (sc + 2 <= nsc) {
+        W64_SUPER(0, 1, 0)
+        W64_SUPER(1, 0, 1)
+    }
+    if (sc < nsc) W64_SUPER(0, 1, 0)
+#undef W64_SUPER
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));             // the last chunks' filler DMA must land before the LDS is given back
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // ... and the filler fragment requests before their registers are reused
+
+    // ---- epilogue: interior tile, blocks of 32 channels (checked by the launcher): conv_igemm_h3's split store
+    uint8_t* __restrict__ tbase = p.y + (long)mtile * 256 * p.y_ld * 4;
+    const unsigned rowb = (unsigned)p.y_ld * 4u;
+    const bool odd = lane & 1;
+    const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+    const float lo_clamp = p.relu ? 0.f : -65504.f;
+    const int ng0 = p.y_coff + ntile * 64 + l16;
+    const unsigned coff0 = (unsigned)((ng0 >> 5) * 128 + (ng0 & 31) * 2 + (odd ? 62 : 0));
+    float vmax = 0.f;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uint8_t* __restrict__ rowp = tbase + ((unsigned)(wave_u * 64 + ii * 16 + 4 * q16 + r) * rowb + coff0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                float v = fmaxf(acc[ii][jj][r] * p.out_scale, lo_clamp);
+                vmax = fmaxf(vmax, fabsf(v));
+                v = fminf(v, 65504.f);
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                *reinterpret_cast<unsigned*>(rowp + ((jj * 16 >> 5) * 128 + ((jj * 16) & 31) * 2)) = __builtin_amdgcn_perm(xn, x, sel);
+            }
+        }
+    if (p.range) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        range_note(p.range, vmax, lane == 0);
+    }
+}
+#undef W64_WAIT4
+#undef W64_PASS
+#undef W64_PASS4
+#undef W64_XC
+#undef W64_BDMA
+#undef W64_BODY
+
 #undef W_RD
 #undef W_XRD
 #undef W_WAIT8

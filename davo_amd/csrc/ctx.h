@@ -120,7 +120,7 @@ struct davo_ctx {
     bool opt_patch_cnv3 = true;                // f16x3: cnv3 likewise (conv_patch_cnv3_h3)
     bool opt_merge_rem = true;                 // f16x3: cnv5 / cnv6 main + remainder launches as one grid (conv_igemm_h3_mainrem)
     int opt_fold_tails = -1;                   // 0 off | 1 both tails | 2 the excitation only | -1 auto: the excitation at small batches (pose_tail.h: what it costs)               // the excitation MLP and the pose head's tile sum run in the last workgroup of the squeeze / cnv7 launch
-    bool opt_wave128 = true;                   // f16x3: cnv5 / cnv6 256x256 tiles on four waves of 128x128 outputs (conv_igemm_h3w.h): -4.6 % per step at B = 32, bit-identical
+    int opt_wave128 = 2;                       // f16x3: cnv5 / cnv6 256x256 tiles on four waves of 128x128 outputs (conv_igemm_h3w.h: -3..5 % per step, bit-identical); 2: their remainder rows on 256x64 tiles too (-1.2 %)
     bool opt_deep_ring = true;                 // f16x3: launches of at most one workgroup per CU (batch 1..4) run on LDS rings of 3..6 slots
     int opt_merge_order = -1;                  // merged grids: 0 = short tiles offset inside every XCD, 1 = per XCD, 2 = main tiles (long first) then the remainder; -1 = 2 where a tile order exists, else 0
     int opt_skip_order = 1;                    // launches whose tiles skip different numbers of padding rows of the filter hand out the long tiles first (tile_order_for, forward.hip): 0 = never, 1 = float32 launches, 2 = the f16x3 merged grids too

@@ -414,10 +414,22 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         const std::string label = i == 0 ? std::string(L.label) : std::string(L.label) + ".rem";
         {
             ProfScope ps(c, label.c_str());
-            if (c->opt_wave128 && plan[i].tile == TILE_256x256 && L.groups == 1 && !fuse_pose && layer_h3w_supported(li, p))
-                HIP_TRY(c, launch_layer_h3w(li, p, grid, c->stream));
-            else
-                HIP_TRY(c, launch_layer_h3(li, plan[i].tile, p, grid, c->stream));
+            bool done = false;
+            if (c->opt_wave128 && L.groups == 1 && !fuse_pose) {
+                if (plan[i].tile == TILE_256x256 && layer_h3w_supported(li, p)) {
+                    HIP_TRY(c, launch_layer_h3w(li, p, grid, c->stream));
+                    done = true;
+                } else if (c->opt_wave128 >= 2 && i == 1 && plan.size() == 2 && plan[0].tile == TILE_256x256 && plan[1].tile == TILE_128x128 &&
+                           L.npad_h == 256 && plan[1].row0 % 256 == 0 && plan[1].rows % 256 == 0) {
+                    // the remainder rows of a layer whose main launch ran on conv_igemm_h3w: 256 x 64 tiles (conv_igemm_h3w64)
+                    ConvParamsH pr = p;
+                    pr.ntiles_n = 4; pr.mtile0 = plan[1].row0 / 256;
+                    const hipError_t e = launch_layer_h3w64(li, pr, c->stream);
+                    if (e == hipSuccess) done = true;
+                    else if (e != hipErrorNotSupported) HIP_TRY(c, e);
+                }
+            }
+            if (!done) HIP_TRY(c, launch_layer_h3(li, plan[i].tile, p, grid, c->stream));
         }
         p.M = full_m;
     }

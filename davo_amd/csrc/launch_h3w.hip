@@ -28,6 +28,27 @@ bool layer_h3w_supported(int layer, const ConvParamsH& p) {
            ((long)p.Mtot << p.x_pix_log2) < 0xFFFFFF00l && 256l * p.w_row_bytes < 0x7FFFFFFFl;     // 32-bit buffer offsets; the marker of an out-of-range row
 }
 
+// the layer's remainder rows on 256 x 64 tiles (conv_igemm_h3w64): grid = 256-row tiles x four N tiles
+template <int LAYER, int RATE>
+static hipError_t launch_w64(const ConvParamsH& p, dim3 grid, hipStream_t s) {
+    auto kern = conv_igemm_h3w64<LAYER, RATE>;
+    constexpr int lds = TileW64<RATE>::LDS_BYTES;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+// p as for the 256x256 tile but with ntiles_n = 4
+hipError_t launch_layer_h3w64(int layer, const ConvParamsH& p, hipStream_t s) {
+    ConvParamsH q = p;
+    q.ntiles_n = 1;
+    if (p.ntiles_n != 4 || !layer_h3w_supported(layer, q)) return hipErrorNotSupported;
+    const dim3 grid((unsigned)((p.M - p.mtile0 * 256) / 256 * 4));
+    if (layer == 4) return launch_w64<5, 8>(p, grid, s);
+    return launch_w64<6, 2>(p, grid, s);
+}
+
 hipError_t launch_layer_h3w(int layer, const ConvParamsH& p, dim3 grid, hipStream_t s) {
     if (!layer_h3w_supported(layer, p) || grid.y != 1) return hipErrorNotSupported;
     if (layer == 4) return launch_w<5, 8>(p, grid, s);

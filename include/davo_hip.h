@@ -282,11 +282,14 @@ const char* davo_range_report(const davo_ctx* ctx);
  *       launches.  Same tiles, same kernels' arithmetic: bit-identical results.
  *   "share_taps" (default 1): cnv3..cnv6 on the 256-row tiles stage ONE pixel patch per filter row for its three kx taps
  *       (csrc/conv_igemm_h3.h, RATE > 0); 0 = a staged chunk per tap.  Bit-identical results.
- *   "wave128" (default 1, round 5): cnv5 / cnv6's launches of whole 256x256 tiles run on FOUR waves of 128x128 outputs each
+ *   "wave128" (default 2, round 5): 1 = cnv5 / cnv6's launches of whole 256x256 tiles run on FOUR waves of 128x128 outputs each
  *       (csrc/conv_igemm_h3w.h: 0.167 LDS fragment reads per matrix instruction instead of 0.25, which is what the power-capped
  *       matrix pipe's rate depends on; one wave per SIMD, every other instruction of the loop in a slot behind one MFMA); the
  *       layer's remainder rows then run as a launch of their own ("merge_rem" does not apply).  Same products in the same order:
  *       bit-identical to 0 = conv_igemm_h3's eight waves of 64x128.  -4.6 % per step at B = 32 (profiles/r05bd_w128_ab.log).
+ *       2 = the remainder rows too leave conv_igemm_h3's 128x128 tiles: 256x64 tiles on four waves of 64x64 outputs, the shared pixel
+ *       patch and deep DMA rings (conv_igemm_h3w64: 19 KB staged per chunk instead of 32; cnv5 / cnv6 remainder 34 / 59 -> 31 / 50 us,
+ *       profiles/r05bh_w64_ab.log).  Bit-identical as well.
  *   "cu_partition" (default 0; with davo_set_inflight(ctx, n > 1)): slot i's stream is CU-masked to its own 1/n of every
  *       XCD's compute units (hipExtStreamCreateWithCUMask) and its launches are planned for that many CUs.  Measured
  *       without gain (HISTORY.md round 2); kept for experiments.  Results do not change.

@@ -1573,10 +1573,11 @@ def test_wave128_tile_is_bit_identical(c_oracle, B, H, W):
         e.set_option("wave128", 0)
         base = e.forward(img, flow, seg).copy()
         acts = {k: e.debug_read(k, (2 * B, h2, w2, c)).copy() for k, c in shapes.items()}
-        e.set_option("wave128", 1)
-        got = e.forward(img, flow, seg)
-        for k, a in acts.items():
-            assert np.array_equal(e.debug_read(k, a.shape), a), (k, tile, merge)
-        assert np.array_equal(got, base)
+        for w in (1, 2):                                     # 2: the remainder rows on conv_igemm_h3w64's 256x64 tiles as well
+            e.set_option("wave128", w)
+            got = e.forward(img, flow, seg)
+            for k, a in acts.items():
+                assert np.array_equal(e.debug_read(k, a.shape), a), (k, tile, merge, w)
+            assert np.array_equal(got, base)
     assert_pose_close(got, c_oracle.forward(cfg, img, flow, seg, weights), "wave128")
     e.close()
