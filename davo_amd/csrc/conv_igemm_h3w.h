@@ -49,7 +49,76 @@ typedef __attribute__((address_space(3))) void w_lds_t;
 // know an inline-asm MFMA for one, so nothing is left to it: every other instruction of the loop sits in a SLOT behind one matrix
 // instruction, pinned by scheduling barriers - at most three vector instructions, the 12 cycles the matrix pipe is busy past the
 // instruction's own issue.  (Second build, each column group's DMA arithmetic in front of its 24 MFMAs: level with conv_igemm_h3.)
+#ifndef DAVO_W_CHMAJOR
+#define DAVO_W_CHMAJOR 0    /* 1: the weights as the matrix instruction's A operand - a lane's accumulator quad is four consecutive CHANNELS of one pixel, 8-byte stores, no lane exchange.  Bit-identical and SLOWER: cnv5 / cnv6 main launches 0.219 / 0.428 -> 0.238 / 0.450 ms, same box (profiles/r05bj_chmajor_ab.log) */
+#endif
+#if DAVO_W_CHMAJOR
+#define W_MFMA1(a_, b_, I_, J_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %1, %0" : "+a"(acc[I_][J_]) : "v"(a_[I_]), "v"(b_))
+#else
 #define W_MFMA1(a_, b_, I_, J_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[I_][J_]) : "v"(a_[I_]), "v"(b_))
+#endif
+// bias into the accumulators and the split store of one wave tile of NI_ x NJ_ quads whose first row / channel are row0_ / ch0_ (tile
+// row, output channel); channel-major quads store 8 bytes of hi halves and 8 of lo halves per quad, with no lane exchange
+#if DAVO_W_CHMAJOR
+#define W_BIAS(NI_, NJ_, ch0_)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) {                                            \
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + (ch0_) + j * 16 + 4 * q16);     \
+        _Pragma("unroll") for (int i = 0; i < (NI_); ++i) {                                        \
+            acc[i][j][0] = b4.x * p.bias_scale; acc[i][j][1] = b4.y * p.bias_scale;                \
+            acc[i][j][2] = b4.z * p.bias_scale; acc[i][j][3] = b4.w * p.bias_scale;                \
+        }                                                                                          \
+    }
+#define W_STORE(NI_, NJ_, row0_, ch0_)                                                             \
+    {                                                                                              \
+        const int cg0 = p.y_coff + (ch0_) + 4 * q16;          /* a multiple of 4; blocks of 32 channels: 64 B of hi halves, 64 B of lo halves */ \
+        const unsigned coff0 = (unsigned)((cg0 >> 5) * 128 + (cg0 & 31) * 2);                      \
+        _Pragma("unroll") for (int ii = 0; ii < (NI_); ++ii) {                                     \
+            uint8_t* __restrict__ rowp = tbase + ((unsigned)((row0_) + ii * 16 + l16) * rowb + coff0);          \
+            _Pragma("unroll") for (int jj = 0; jj < (NJ_); ++jj) {                                 \
+                unsigned short h_[4], l_[4];                                                       \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
+                    float v = fmaxf(acc[ii][jj][r] * p.out_scale, lo_clamp);                       \
+                    vmax = fmaxf(vmax, fabsf(v));                                                  \
+                    v = fminf(v, 65504.f);                                                         \
+                    const _Float16 hi = (_Float16)v;                                               \
+                    const _Float16 lo = (_Float16)(v - (float)hi);                                 \
+                    h_[r] = __builtin_bit_cast(unsigned short, hi); l_[r] = __builtin_bit_cast(unsigned short, lo); \
+                }                                                                                  \
+                uint8_t* q_ = rowp + ((jj * 16 >> 5) * 128 + ((jj * 16) & 31) * 2);                \
+                *reinterpret_cast<uint2*>(q_) = make_uint2((unsigned)h_[0] | ((unsigned)h_[1] << 16), (unsigned)h_[2] | ((unsigned)h_[3] << 16));       \
+                *reinterpret_cast<uint2*>(q_ + 64) = make_uint2((unsigned)l_[0] | ((unsigned)l_[1] << 16), (unsigned)l_[2] | ((unsigned)l_[3] << 16));  \
+            }                                                                                      \
+        }                                                                                          \
+    }
+#else
+#define W_BIAS(NI_, NJ_, ch0_)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) {                                            \
+        const float bv = p.bias[(ch0_) + j * 16 + l16] * p.bias_scale;                             \
+        _Pragma("unroll") for (int i = 0; i < (NI_); ++i)                                          \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[i][j][r] = bv;                       \
+    }
+#define W_STORE(NI_, NJ_, row0_, ch0_)                                                             \
+    {                                                                                              \
+        const bool odd = lane & 1;                                                                 \
+        const unsigned sel = odd ? 0x03020706u : 0x05040100u;                                      \
+        const int ng0 = p.y_coff + (ch0_) + l16;                                                   \
+        const unsigned coff0 = (unsigned)((ng0 >> 5) * 128 + (ng0 & 31) * 2 + (odd ? 62 : 0));     \
+        _Pragma("unroll") for (int ii = 0; ii < (NI_); ++ii)                                       \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                        \
+                uint8_t* __restrict__ rowp = tbase + ((unsigned)((row0_) + ii * 16 + 4 * q16 + r) * rowb + coff0);          \
+                _Pragma("unroll") for (int jj = 0; jj < (NJ_); ++jj) {                             \
+                    float v = fmaxf(acc[ii][jj][r] * p.out_scale, lo_clamp);                       \
+                    vmax = fmaxf(vmax, fabsf(v));                                                  \
+                    v = fminf(v, 65504.f);                                                         \
+                    const _Float16 hi = (_Float16)v;                                               \
+                    const _Float16 lo = (_Float16)(v - (float)hi);                                 \
+                    const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16); \
+                    const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   /* quad_perm [1,0,3,2] */ \
+                    *reinterpret_cast<unsigned*>(rowp + ((jj * 16 >> 5) * 128 + ((jj * 16) & 31) * 2)) = __builtin_amdgcn_perm(xn, x, sel); \
+                }                                                                                  \
+            }                                                                                      \
+    }
+#endif
 #define W_SLOT(a_, b_, I_, J_, STMT_) W_MFMA1(a_, b_, I_, J_); W_SB; STMT_; W_SB;
 #define W_PASS(a_, b_, J_)                                                                         \
     { W_MFMA1(a_, b_, 0, J_); W_MFMA1(a_, b_, 1, J_); W_MFMA1(a_, b_, 2, J_); W_MFMA1(a_, b_, 3, J_);   \
@@ -236,17 +305,7 @@ __device__ __forceinline__ void conv_igemm_h3w_body(const ConvParamsH& p, const 
     for (int pl = 0; pl < 2; ++pl) foff16[pl] = ((pl * 4 + q16) ^ ((l16 >> 1) & 7)) * 16;
 
     f32x4 acc[8][8];
-    {
-        const float inv = p.bias_scale;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float bv = p.bias[wn * 128 + j * 16 + l16] * inv;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = bv;
-        }
-    }
+    W_BIAS(8, 8, wn * 128)
     half8 AH[2][8], AL[2][8], bh[8], bl[8];
 
     // ---- prologue: the first patch, the first weight chunk; then the first chunk's first fragments
@@ -303,32 +362,12 @@ __device__ __forceinline__ void conv_igemm_h3w_body(const ConvParamsH& p, const 
     __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));             // the last chunk's filler DMA must land before the LDS is given back
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // ... and its filler fragment requests before their registers are reused
 
-    // ---- epilogue: interior tile, blocks of 32 channels (checked by the launcher): conv_igemm_h3's split store
+    // ---- epilogue: interior tile, blocks of 32 channels (checked by the launcher): the split store
     uint8_t* __restrict__ tbase = p.y + (long)mtile * 256 * p.y_ld * 4;
     const unsigned rowb = (unsigned)p.y_ld * 4u;
-    const bool odd = lane & 1;
-    const unsigned sel = odd ? 0x03020706u : 0x05040100u;
     const float lo_clamp = p.relu ? 0.f : -65504.f;
-    const int ng0 = p.y_coff + wn * 128 + l16;
-    const unsigned coff0 = (unsigned)((ng0 >> 5) * 128 + (ng0 & 31) * 2 + (odd ? 62 : 0));
     float vmax = 0.f;
-#pragma unroll
-    for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            uint8_t* __restrict__ rowp = tbase + ((unsigned)(wm * 128 + ii * 16 + 4 * q16 + r) * rowb + coff0);
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                float v = fmaxf(acc[ii][jj][r] * p.out_scale, lo_clamp);
-                vmax = fmaxf(vmax, fabsf(v));
-                v = fminf(v, 65504.f);
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                *reinterpret_cast<unsigned*>(rowp + ((jj * 16 >> 5) * 128 + ((jj * 16) & 31) * 2)) = __builtin_amdgcn_perm(xn, x, sel);
-            }
-        }
+    W_STORE(8, 8, wm * 128, wn * 128)
     if (p.range) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
@@ -503,17 +542,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_h3w64(ConvParamsH p) {
     for (int pl = 0; pl < 2; ++pl) foff16[pl] = ((pl * 4 + q16) ^ ((l16 >> 1) & 7)) * 16;
 
     f32x4 acc[4][4];
-    {
-        const float inv = p.bias_scale;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float bv = p.bias[ntile * 64 + j * 16 + l16] * inv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = bv;
-        }
-    }
+    W_BIAS(4, 4, ntile * 64)
     half8 AH[2][4], AL[2][4], bh[4], bl[4];
 
     // (channel block, filter row) of a super-chunk; super-chunks past the end repeat the last one (their DMA is never read)
@@ -588,32 +617,12 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_h3w64(ConvParamsH p) {
     __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));             // the last chunks' filler DMA must land before the LDS is given back
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // ... and the filler fragment requests before their registers are reused
 
-    // ---- epilogue: interior tile, blocks of 32 channels (checked by the launcher): conv_igemm_h3's split store
+    // ---- epilogue: interior tile, blocks of 32 channels (checked by the launcher): the split store
     uint8_t* __restrict__ tbase = p.y + (long)mtile * 256 * p.y_ld * 4;
     const unsigned rowb = (unsigned)p.y_ld * 4u;
-    const bool odd = lane & 1;
-    const unsigned sel = odd ? 0x03020706u : 0x05040100u;
     const float lo_clamp = p.relu ? 0.f : -65504.f;
-    const int ng0 = p.y_coff + ntile * 64 + l16;
-    const unsigned coff0 = (unsigned)((ng0 >> 5) * 128 + (ng0 & 31) * 2 + (odd ? 62 : 0));
     float vmax = 0.f;
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            uint8_t* __restrict__ rowp = tbase + ((unsigned)(wave_u * 64 + ii * 16 + 4 * q16 + r) * rowb + coff0);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                float v = fmaxf(acc[ii][jj][r] * p.out_scale, lo_clamp);
-                vmax = fmaxf(vmax, fabsf(v));
-                v = fminf(v, 65504.f);
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                const unsigned x = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                const unsigned xn = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                *reinterpret_cast<unsigned*>(rowp + ((jj * 16 >> 5) * 128 + ((jj * 16) & 31) * 2)) = __builtin_amdgcn_perm(xn, x, sel);
-            }
-        }
+    W_STORE(4, 4, wave_u * 64, ntile * 64)
     if (p.range) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
@@ -634,6 +643,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_h3w64(ConvParamsH p) {
 #undef W_WAIT2
 #undef W_PASS
 #undef W_MFMA1
+#undef W_BIAS
+#undef W_STORE
 #undef W_SLOT
 #undef W_PASS8
 #undef W_NOP
