@@ -636,6 +636,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_h3w64(ConvParamsH p) {
 #undef W64_BDMA
 #undef W64_BODY
 
+
+
 #undef W_RD
 #undef W_XRD
 #undef W_WAIT8

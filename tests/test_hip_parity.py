@@ -1581,3 +1581,4 @@ def test_wave128_tile_is_bit_identical(c_oracle, B, H, W):
             assert np.array_equal(got, base)
     assert_pose_close(got, c_oracle.forward(cfg, img, flow, seg, weights), "wave128")
     e.close()
+
