@@ -278,7 +278,10 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
     if (const char* e = tuning_env("DAVO_DBG")) p.dbg = atoi(e);       // tuning build only
     // cnv5, cnv6, cnv7 (256 channels per group) and cnv4 (128): conv_igemm_h3s.h is instantiated for them
     const bool allow_208 = (li >= 4 && L.npad_h == 256) || (li == 3 && L.npad_h == 128 && c->opt_tile_208x128);
-    std::vector<LaunchH> plan = plan_layer_h3(p.M, L.npad_h, L.groups, L.tile_h, allow_208, c->ncu);
+    // cnv5 / cnv6 with "wave128": the 256x256 tile is conv_igemm_h3w's, 4.7 % faster than the one the planner's table was fitted on
+    // (measured across 21 batch sizes with the table scaled: only B = 24 and 256x832 B = 6 change plan, -2.7 / -3.2 %: profiles/r05bn_planner_scale.log)
+    const double others_scale = (c->opt_wave128 && (li == 4 || li == 5) && L.npad_h == 256 && L.groups == 1 && !fuse_pose) ? 0.955 : 1.0;
+    std::vector<LaunchH> plan = plan_layer_h3(p.M, L.npad_h, L.groups, L.tile_h, allow_208, c->ncu, others_scale);
     if (fuse_pose) {      // one launch, one tile shape no taller than an image, so a tile touches <= 2 images
         const int P = Ho * Wo;
         const int best = plan_single_tile_h3(p.M, L.npad_h, L.groups, P, L.tile_h, allow_208, c->ncu);

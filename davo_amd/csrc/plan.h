@@ -37,7 +37,9 @@ const TileInfo* h3_tiles(int* n);
 // main launch + optional remainder launch for an M x npad (x groups) layer; forced_tile >= 0: one launch of that tile
 // allow_208: the layer has a conv_igemm_h3s instantiation for its width (3x3, Cin >= 32: cnv5, cnv6, cnv7 at 256 output channels
 // per group -> TILE_208x256; cnv4 at 128 -> TILE_208x128)
-std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile, bool allow_208 = false, int ncu = 256);
+// others_scale: the efficiencies of every tile but 256x256 are multiplied by it (cnv5 / cnv6 with "wave128": their 256x256 launches run
+// on conv_igemm_h3w, 4.7 % faster than the kernel the table was fitted on)
+std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile, bool allow_208 = false, int ncu = 256, double others_scale = 1.0);
 // one launch, one tile shape no taller than max_bm rows (fused pose head: a tile touches <= 2 images); -1 if none fits
 int plan_single_tile_h3(int M, int npad, int groups, int max_bm, int forced_tile, bool allow_208 = false, int ncu = 256);
 

@@ -115,8 +115,13 @@ double h3_cost(const TileInfo& t, long ntiles, int ncu) {
     return (double)full * t.per_cu * one + (double)((rest + ncu - 1) / ncu) * one;
 }
 
-std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile, bool allow_208, int ncu) {
+std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile, bool allow_208, int ncu, double others_scale) {
     tiles_from_env();
+    TileInfo tiles[sizeof kTiles / sizeof kTiles[0]];
+    for (size_t i = 0; i < sizeof kTiles / sizeof kTiles[0]; ++i) {
+        tiles[i] = kTiles[i];
+        if (tiles[i].id != TILE_256x256) tiles[i].eff *= others_scale;
+    }
     auto ntiles = [&](const TileInfo& t, int rows) {
         const TileShape ts = tile_shape(t.id);
         return (long)((rows + ts.bm - 1) / ts.bm) * (npad / ts.bn) * groups;
@@ -130,7 +135,7 @@ std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile,
     double best_cost = 1e30;
     const char* rf = tuning_env("DAVO_H3_REM_TILE");
     const int rem_force = rf ? atoi(rf) : -1;
-    for (const TileInfo& t1 : kTiles) {
+    for (const TileInfo& t1 : tiles) {
         if (!fits(t1)) continue;
         const double c1 = h3_cost(t1, ntiles(t1, M), ncu);
         if (c1 < best_cost - 1e-9) { best_cost = c1; best = {{0, M, t1.id}}; }
@@ -144,7 +149,7 @@ std::vector<LaunchH> plan_layer_h3(int M, int npad, int groups, int forced_tile,
         rows1 -= rows1 % 256;                                             // every tile height divides 256
         if (rows1 <= 0 || rows1 >= M) continue;
         const double cm = h3_cost(t1, ntiles(t1, rows1), ncu);
-        for (const TileInfo& t2 : kTiles) {
+        for (const TileInfo& t2 : tiles) {
             if (!fits(t2) || is_208(t2.id)) continue;
             if (rem_force >= 0 && t2.id != rem_force) continue;
             const double c = cm + h3_cost(t2, ntiles(t2, M - rows1), ncu) + 0.08;      // a second launch: its fill/drain and the kernel boundary
