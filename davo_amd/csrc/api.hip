@@ -986,7 +986,7 @@ int davo_set_option(davo_ctx* c, const char* key, int value) {
     else if (k == "patch_cnv3") c->opt_patch_cnv3 = value != 0;
     else if (k == "fold_tails") c->opt_fold_tails = value < 0 ? -1 : (value > 2 ? 1 : value);
     else if (k == "deep_ring") c->opt_deep_ring = value != 0;
-    else if (k == "wave128") c->opt_wave128 = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (k == "wave128") c->opt_wave128 = value < 0 ? 0 : (value > 3 ? 3 : value);      // 3: cnv4 on conv_igemm_h3w128 whatever the round count (test hook)
     else if (k == "split_k") c->opt_split_k = value != 0;
     else if (k == "fold_fixup") c->opt_fold_fixup = value != 0;
     else if (k == "f32_n16") c->opt_f32_n16 = value != 0;

@@ -649,6 +649,273 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_h3w64(ConvParamsH p) {
 
 
 
+
+// ---- cnv4 (3x3, dilation 4, 64 -> 128 channels) on 256 x 128 tiles (conv_igemm_h3w128) -----------------------------------------
+// cnv4 on conv_igemm_h3's 128x128 tiles (two workgroups per CU, two ring slots) takes 1.6 us per chunk and workgroup for 0.38 us of
+// matrix work: 32 KB staged per 3.1 MFLOP, at what a CU takes in from L2.  A 256-row tile with the shared pixel patch stages 11 KB of
+// pixels and 16 KB of weights per chunk for twice the work - 2.3 x fewer bytes per FLOP.  (conv_igemm_h3's own 256x128 tile has that
+// ratio too and measured level: one workgroup per CU with two ring slots has one chunk in flight.)  Four waves of 128 x 64 outputs,
+// conv_igemm_h3w's slots and barrier placement, and as many bytes in flight as the LDS holds: two patch buffers (the next super-chunk's
+// patch is issued during the first two chunks of this one) and a weight ring of FIVE slots, four chunks ahead; the wait in front of the
+// barrier is counted per tap (first build: three patch buffers, weights two ahead, one chunk's DMA in flight: 1.2 us per chunk).
+template <int RATE> struct TileW128 {
+    static constexpr int PR = TileW<RATE>::PR, PATCH = PR * 128, BSLOT = 128 * 128, NB = 5, NP = 2;
+    static constexpr int LDS_BYTES = NP * PATCH + NB * BSLOT + 4 * 1024 + 128;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS per workgroup");
+};
+
+#define W128_BDMA(j_, slot_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (w_lds_t*)(Bs + (slot_) * TW::BSLOT + ((j_) * 32 + 8 * wave_u) * 128), 16, boff[j_], wsoff, 0, 0)
+#define W128_XC(t_, j_, abuf_)                                                                     \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (w_lds_t*)(((j_) < 8 || (8 * wave_u + (j_) * 32) < PR)                     \
+                                                     ? As + (abuf_) * TW::PATCH + ((j_) * 32 + 8 * wave_u) * 128 : xdummy + wave_u * 1024), \
+                                             16, ((j_) < 8 || (8 * wave_u + (j_) * 32) < PR) ? xvo##t_ : 0xFFFFFF00u, 0, 0, 0)
+// the DMA of one chunk, by tap: kx = 0 five patch slots of the next super-chunk, kx = 1 the other four, kx = 2 none; then the four
+// weight pieces of the chunk four ahead.  24 slots of column group 1.
+#define W128_DMA_0                                                                                  \
+        W_PASS8(AH[CUR__], bh[1], 1, W_XA(0, 0), W_XB(0, 0), W128_XC(0, 0, nabuf), W_XA(1, 1), W_XB(1, 1), W128_XC(1, 1, nabuf), W_XA(2, 2), W_XB(2, 2)) \
+        W_PASS8(AH[CUR__], bl[1], 1, W128_XC(2, 2, nabuf), W_XA(3, 3), W_XB(3, 3), W128_XC(3, 3, nabuf), W_XA(4, 4), W_XB(4, 4), W128_XC(4, 4, nabuf), W128_BDMA(0, wdst)) \
+        W_PASS8(AL[CUR__], bh[1], 1, W128_BDMA(1, wdst), W128_BDMA(2, wdst), W128_BDMA(3, wdst), W_NOP, W_NOP, W_NOP, W_NOP, W_NOP)
+#define W128_DMA_1                                                                                  \
+        W_PASS8(AH[CUR__], bh[1], 1, W_XA(5, 5), W_XB(5, 5), W128_XC(5, 5, nabuf), W_XA(6, 6), W_XB(6, 6), W128_XC(6, 6, nabuf), W_XA(7, 7), W_XB(7, 7)) \
+        W_PASS8(AH[CUR__], bl[1], 1, W128_XC(7, 7, nabuf), W_XA(8, 8), W_XB(8, 8), W128_XC(8, 8, nabuf), W128_BDMA(0, wdst), W128_BDMA(1, wdst), W128_BDMA(2, wdst), W128_BDMA(3, wdst)) \
+        W_PASS(AL[CUR__], bh[1], 1)
+#define W128_DMA_2                                                                                  \
+        W_PASS8(AH[CUR__], bh[1], 1, W128_BDMA(0, wdst), W128_BDMA(1, wdst), W128_BDMA(2, wdst), W128_BDMA(3, wdst), W_NOP, W_NOP, W_NOP, W_NOP) \
+        W_PASS(AH[CUR__], bl[1], 1) W_PASS(AL[CUR__], bh[1], 1)
+// vmcnt allowed in front of the barrier of tap kx: the next chunk's weights were issued three chunks ago (the DMA of the newest three
+// chunks may be in flight: 8 + 4 + 9 instructions); after kx = 2 the next patch - its last pieces are chunk kx = 1's first DMA
+// instructions - must have landed as well: only the weight pieces of chunks kx = 1 and kx = 2 may be in flight
+#define W128_VM_0 21
+#define W128_VM_1 21
+#define W128_VM_2 8
+#define W128_BODY(KX_, CUR_)                                                                       \
+    {                                                                                              \
+        constexpr int NKX_ = ((KX_) + 1) % 3;                                                      \
+        constexpr int CUR__ = CUR_;                                                                \
+        const unsigned b0_ = lds_u32(Bs + wslot * TW::BSLOT + (wn * 64 + l16) * 128);              \
+        const unsigned b_h = b0_ + foff16[0], b_l = b0_ + foff16[1];                               \
+        /* weights of chunk q + 4: tap (kx + 1) % 3 of the next super-chunk (of the one after it for kx = 2) -> the slot the chunk before used */ \
+        const unsigned wsoff = ((KX_) == 2 ? w2 : w1) + NKX_ * 128;                                \
+        const int wdst = wslot == 0 ? TW::NB - 1 : wslot - 1;                                      \
+        /* ---- column group 0 */                                                                  \
+        W_RD(bh[2], b_h, 2 * 2048); W_RD(bl[2], b_l, 2 * 2048);                                    \
+        W_WAIT8(13, AH[CUR_]); W_WAIT1(13, bh[0]);                                                 \
+        W_PASS(AH[CUR_], bh[0], 0)                                                                 \
+        W_SB;                                                                                      \
+        W_WAIT1(12, bl[0]);                                                                        \
+        W_PASS(AH[CUR_], bl[0], 0)                                                                 \
+        W_SB;                                                                                      \
+        W_WAIT8(4, AL[CUR_]);                                                                      \
+        W_PASS(AL[CUR_], bh[0], 0)                                                                 \
+        W_SB;                                                                                      \
+        /* ---- column group 1: the chunk's DMA */                                                 \
+        W_RD(bh[3], b_h, 3 * 2048); W_RD(bl[3], b_l, 3 * 2048);                                    \
+        W_WAIT2(4, bh[1], bl[1]);                                                                  \
+        W128_DMA_##KX_                                                                             \
+        W_SB;                                                                                      \
+        /* ---- column group 2 */                                                                  \
+        W_WAIT2(2, bh[2], bl[2]);                                                                  \
+        W_PASS(AH[CUR_], bh[2], 2) W_PASS(AH[CUR_], bl[2], 2) W_PASS(AL[CUR_], bh[2], 2)           \
+        W_SB;                                                                                      \
+        W_WAIT2(0, bh[3], bl[3]);                                                                  \
+        /* ---- column group 3 */                                                                  \
+        {                                                                                          \
+            __builtin_amdgcn_s_waitcnt((W128_VM_##KX_ & 15) | (7 << 4) | (15 << 8) | ((W128_VM_##KX_ >> 4) << 14));             \
+            __builtin_amdgcn_s_barrier();                                                          \
+            const unsigned pb_ = lds_u32(As + ((KX_) == 2 ? nabuf : abuf) * TW::PATCH);            \
+            const int nrow_ = xrow0 + NKX_ * RATE;                                                 \
+            const unsigned na_h = pb_ + (unsigned)(nrow_ * 128 + ((q16 ^ (nrow_ & 6)) * 16));      \
+            const unsigned na_l = pb_ + (unsigned)(nrow_ * 128 + (((4 + q16) ^ (nrow_ & 6)) * 16)); \
+            const int nws_ = wslot + 1 == TW::NB ? 0 : wslot + 1;                                  \
+            const unsigned nb0_ = lds_u32(Bs + nws_ * TW::BSLOT + (wn * 64 + l16) * 128);          \
+            const unsigned nb_h = nb0_ + foff16[0], nb_l = nb0_ + foff16[1];                       \
+            W_SB;                                                                                  \
+            W_PASS8(AH[CUR_], bh[3], 3, W_XRD(AH[(CUR_) ^ 1][0], 0, na_h, NKX_), W_XRD(AH[(CUR_) ^ 1][1], 1, na_h, NKX_),       \
+                    W_XRD(AH[(CUR_) ^ 1][2], 2, na_h, NKX_), W_XRD(AH[(CUR_) ^ 1][3], 3, na_h, NKX_), W_XRD(AH[(CUR_) ^ 1][4], 4, na_h, NKX_), \
+                    W_XRD(AH[(CUR_) ^ 1][5], 5, na_h, NKX_), W_XRD(AH[(CUR_) ^ 1][6], 6, na_h, NKX_), W_XRD(AH[(CUR_) ^ 1][7], 7, na_h, NKX_)) \
+            W_PASS8(AH[CUR_], bl[3], 3, W_RD(bh[0], nb_h, 0), W_RD(bl[0], nb_l, 0),                \
+                    W_XRD(AL[(CUR_) ^ 1][0], 0, na_l, NKX_), W_XRD(AL[(CUR_) ^ 1][1], 1, na_l, NKX_), W_XRD(AL[(CUR_) ^ 1][2], 2, na_l, NKX_), \
+                    W_XRD(AL[(CUR_) ^ 1][3], 3, na_l, NKX_), W_XRD(AL[(CUR_) ^ 1][4], 4, na_l, NKX_), W_XRD(AL[(CUR_) ^ 1][5], 5, na_l, NKX_)) \
+            W_PASS8(AL[CUR_], bh[3], 3, W_XRD(AL[(CUR_) ^ 1][6], 6, na_l, NKX_), W_XRD(AL[(CUR_) ^ 1][7], 7, na_l, NKX_),       \
+                    W_RD(bh[1], nb_h, 2048), W_RD(bl[1], nb_l, 2048), W_NOP, W_NOP, W_NOP, W_NOP)  \
+        }                                                                                          \
+        W_SB;                                                                                      \
+        wslot = wslot + 1 == TW::NB ? 0 : wslot + 1;                                               \
+    }
+
+template <int LAYER, int RATE>
+__global__ __launch_bounds__(256, 1) void conv_igemm_h3w128(ConvParamsH p) {
+    using TW = TileW128<RATE>;
+    constexpr int PR = TW::PR;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_w8[];
+    uint8_t* As = smem_w8;                              // [2][PR][128] pixel patches
+    uint8_t* Bs = smem_w8 + TW::NP * TW::PATCH;         // [5][128][128] weight ring
+    uint8_t* xdummy = Bs + TW::NB * TW::BSLOT;          // 1 KB per wave: where a patch slot past the patch's end lands
+    const unsigned xzero = lds_u32(xdummy + 4 * 1024);  // 128 zero bytes (what a tap reads outside its image row)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave_u >> 1, wn = wave_u & 1;
+    const int l16 = lane & 15, q16 = lane >> 4;
+    if (tid < 8) *reinterpret_cast<float4*>(xdummy + 4 * 1024 + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int mtile = p.mtile0 + xcd_remap(blockIdx.x, gridDim.x);       // one N tile: N = 128
+    const uint8_t* __restrict__ xg = p.x + p.x_boff;
+    const uint8_t* __restrict__ wg = p.w;
+    int ky0, nky;
+    {
+        const FilterRows fr = valid_filter_rows(mtile * 256, mtile * 256 + 255, p.Hout, p.Wout, p.Hin, 1, p.pad_t, p.rate);
+        ky0 = __builtin_amdgcn_readfirstlane(fr.ky0);
+        nky = __builtin_amdgcn_readfirstlane(fr.nky);
+    }
+    const int nsc = (p.nchunks / 9) * nky;
+
+    const int r0 = tid >> 3;
+    unsigned boff[4];
+    {
+        const int u = (tid & 7) ^ ((r0 >> 1) & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) boff[j] = (unsigned)((r0 + 32 * j) * (int)p.w_row_bytes + u * 16);
+    }
+    const int ux = (tid & 7) ^ (r0 & 6);
+    unsigned poff[9];
+    int xyv[9];
+    {
+        const int hw = p.Hout * p.Wout;
+        const unsigned uoff = (unsigned)((ux >> 2) * 64 + (ux & 3) * 16);
+        const int q32 = 32 / p.Wout, r32 = 32 - q32 * p.Wout;
+        int n = 0, y = 0, x = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int row = r0 + 32 * j;
+            const int f = mtile * 256 - RATE + row;
+            const bool ok = row < PR && f >= 0 && f < p.Mtot;
+            if (j < 2) {
+                const int fc = f >= 0 ? f : 0;
+                n = fc / hw;
+                const int rem = fc - n * hw;
+                y = rem / p.Wout;
+                x = rem - y * p.Wout;
+            } else {
+                x += r32; y += q32;
+                if (x >= p.Wout) { x -= p.Wout; ++y; }
+                if (y >= p.Hout) { y -= p.Hout; ++n; }
+            }
+            poff[j] = ((unsigned)((n * p.Hin + y - RATE) * p.Win + x) << p.x_pix_log2) + uoff;
+            xyv[j] = ok ? y - RATE : -(1 << 28);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(xg), 0, (int)((unsigned)p.Mtot << p.x_pix_log2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wg), 0, (int)(128u * (unsigned)p.w_row_bytes), 0x00020000);
+    const int xrow0 = wm * 128 + l16;
+    unsigned xkeep = 0;
+    {
+        int x = (mtile * 256 + xrow0) % p.Wout;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (x >= RATE) xkeep |= 1u << i;
+            if (x < p.Wout - RATE) xkeep |= 1u << (8 + i);
+            x += 16;
+            if (x >= p.Wout) x -= p.Wout;
+        }
+    }
+    int foff16[2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) foff16[pl] = ((pl * 4 + q16) ^ ((l16 >> 1) & 7)) * 16;
+
+    f32x4 acc[8][4];
+    W_BIAS(8, 4, wn * 64)
+    half8 AH[2][8], AL[2][8], bh[4], bl[4];
+
+    auto sc_coords = [&](int s, int& cblk, int& ky) {
+        const int sv = s < nsc ? s : nsc - 1;
+        cblk = sv / nky;
+        ky = ky0 + (sv - cblk * nky);
+    };
+    auto w_at = [](int cb, int ky) { return (unsigned)((cb * 3 + ky) * 3) * 128u; };
+
+    // ---- prologue: the first patch, the weights of chunks 0..3; then the first chunk's first fragments
+    int cb1, ky1, cb2, ky2;                               // coordinates of super-chunks sc + 1 and sc + 2, walked without divisions
+    sc_coords(1, cb1, ky1);
+    sc_coords(2, cb2, ky2);
+    {
+        const int xdy = ky0 * RATE;
+        const unsigned xsoff = (unsigned)(ky0 * RATE * p.Win) << p.x_pix_log2;
+        W_XA(0, 0); W_XB(0, 0); W128_XC(0, 0, 0); W_XA(1, 1); W_XB(1, 1); W128_XC(1, 1, 0); W_XA(2, 2); W_XB(2, 2); W128_XC(2, 2, 0);
+        W_XA(3, 3); W_XB(3, 3); W128_XC(3, 3, 0); W_XA(4, 4); W_XB(4, 4); W128_XC(4, 4, 0); W_XA(5, 5); W_XB(5, 5); W128_XC(5, 5, 0);
+        W_XA(6, 6); W_XB(6, 6); W128_XC(6, 6, 0); W_XA(7, 7); W_XB(7, 7); W128_XC(7, 7, 0); W_XA(8, 8); W_XB(8, 8); W128_XC(8, 8, 0);
+        const unsigned wa = w_at(0, ky0), wb = w_at(cb1, ky1);
+        { const unsigned wsoff = wa; W128_BDMA(0, 0); W128_BDMA(1, 0); W128_BDMA(2, 0); W128_BDMA(3, 0); }
+        { const unsigned wsoff = wa + 128; W128_BDMA(0, 1); W128_BDMA(1, 1); W128_BDMA(2, 1); W128_BDMA(3, 1); }
+        { const unsigned wsoff = wa + 256; W128_BDMA(0, 2); W128_BDMA(1, 2); W128_BDMA(2, 2); W128_BDMA(3, 2); }
+        { const unsigned wsoff = wb; W128_BDMA(0, 3); W128_BDMA(1, 3); W128_BDMA(2, 3); W128_BDMA(3, 3); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));             // vmcnt(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the zero row's ds_write
+    __builtin_amdgcn_s_barrier();
+    {
+        const unsigned pb_ = lds_u32(As);
+        const unsigned na_h = pb_ + (unsigned)(xrow0 * 128 + ((q16 ^ (xrow0 & 6)) * 16));
+        const unsigned na_l = pb_ + (unsigned)(xrow0 * 128 + (((4 + q16) ^ (xrow0 & 6)) * 16));
+        const unsigned nb0_ = lds_u32(Bs + (wn * 64 + l16) * 128);
+        W_XRD(AH[0][0], 0, na_h, 0) W_XRD(AH[0][1], 1, na_h, 0) W_XRD(AH[0][2], 2, na_h, 0) W_XRD(AH[0][3], 3, na_h, 0)
+        W_XRD(AH[0][4], 4, na_h, 0) W_XRD(AH[0][5], 5, na_h, 0) W_XRD(AH[0][6], 6, na_h, 0) W_XRD(AH[0][7], 7, na_h, 0)
+        W_RD(bh[0], nb0_ + foff16[0], 0); W_RD(bl[0], nb0_ + foff16[1], 0);
+        W_XRD(AL[0][0], 0, na_l, 0) W_XRD(AL[0][1], 1, na_l, 0) W_XRD(AL[0][2], 2, na_l, 0) W_XRD(AL[0][3], 3, na_l, 0)
+        W_XRD(AL[0][4], 4, na_l, 0) W_XRD(AL[0][5], 5, na_l, 0) W_XRD(AL[0][6], 6, na_l, 0) W_XRD(AL[0][7], 7, na_l, 0)
+        W_RD(bh[1], nb0_ + foff16[0], 2048); W_RD(bl[1], nb0_ + foff16[1], 2048);
+    }
+    W_SB;
+
+    // ---- main loop
+    int wslot = 0;                                        // ring slot of the current chunk's weights
+#define W128_SUPER(P0_, P1_, P2_)                                                                  \
+    {                                                                                              \
+        const int xdy = sc + 1 < nsc ? ky1 * RATE : -(1 << 28);      /* the super-chunk whose patch this one fetches */ \
+        const unsigned xsoff = ((unsigned)(ky1 * RATE * p.Win) << p.x_pix_log2) + (unsigned)cb1 * 128u;       \
+        const unsigned w1 = w_at(cb1, ky1), w2 = w_at(cb2, ky2);                                   \
+        const int abuf = sc & 1, nabuf = abuf ^ 1;                                                 \
+        W128_BODY(0, P0_) W128_BODY(1, P1_) W128_BODY(2, P2_)                                      \
+        cb1 = cb2; ky1 = ky2;                                                                      \
+        if (sc + 3 < nsc) { if (++ky2 == ky0 + nky) { ky2 = ky0; ++cb2; } }                        \
+        ++sc;                                                                                      \
+    }
+    int sc = 0;
+    while (sc + 2 <= nsc) {
+        W128_SUPER(0, 1, 0)
+        W128_SUPER(1, 0, 1)
+    }
+    if (sc < nsc) W128_SUPER(0, 1, 0)
+#undef W128_SUPER
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));             // the last chunks' filler DMA must land before the LDS is given back
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // ... and the filler fragment requests before their registers are reused
+
+    // ---- epilogue: interior tile, blocks of 32 channels (checked by the launcher): the split store
+    uint8_t* __restrict__ tbase = p.y + (long)mtile * 256 * p.y_ld * 4;
+    const unsigned rowb = (unsigned)p.y_ld * 4u;
+    const float lo_clamp = p.relu ? 0.f : -65504.f;
+    float vmax = 0.f;
+    W_STORE(8, 4, wm * 128, wn * 64)
+    if (p.range) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        range_note(p.range, vmax, lane == 0);
+    }
+}
+#undef W128_BDMA
+#undef W128_XC
+#undef W128_DMA_0
+#undef W128_DMA_1
+#undef W128_DMA_2
+#undef W128_VM_0
+#undef W128_VM_1
+#undef W128_VM_2
+#undef W128_BODY
+
 #undef W_RD
 #undef W_XRD
 #undef W_WAIT8

@@ -311,6 +311,24 @@ int run_conv_layer_h3(davo_ctx* c, int li, const void* x, int x_ch, int Hin, int
         if (pose_ntn) *pose_ntn = ntn;
     }
     c->last_plan[li][0] = c->last_plan[li][1] = 0;
+    // cnv4 on conv_igemm_h3w128's 256 x 128 tiles, every row in one launch - where the 256-row tiles fill whole rounds of the CUs or
+    // nearly so: a round of them takes 24.4 us against 29.2 for the same rows on conv_igemm_h3's tiles (B = 128: 0.385 -> 0.318 ms),
+    // which a last round that is three quarters empty gives back (B = 32, 3.25 rounds: 0.0925 -> 0.0938 ms)
+    const long t256 = (p.M + 255) / 256;
+    const bool rounds_ok = t256 >= c->ncu && (double)((t256 + c->ncu - 1) / c->ncu) * c->ncu <= 1.12 * (double)t256;
+    if ((c->opt_wave128 >= 3 || (c->opt_wave128 >= 2 && rounds_ok)) && li == 3 && !fuse_pose && L.groups == 1 && L.npad_h == 128 && L.tile_h < 0 &&
+        p.M >= 256 * c->ncu) {
+        ConvParamsH pw = p;
+        pw.ntiles_n = 1; pw.mtile0 = 0;
+        if (layer_h3w128_supported(pw)) {
+            {
+                ProfScope ps(c, L.label);
+                HIP_TRY(c, launch_layer_h3w128(pw, c->stream));
+            }
+            c->last_plan[li][0] = ((p.M + 127) / 128) * 1000 + TILE_256x128;
+            return DAVO_OK;
+        }
+    }
     if (c->opt_merge_cnv4 && c->opt_merge_rem && li == 3 && !fuse_pose && L.npad_h == 128 && L.groups == 1 && c->ncu == 256 && L.tile_h < 0 &&
         plan.size() == 1 && plan[0].tile == TILE_128x128) {
         // cnv4 (N = 128): whole rounds of 256x128 tiles (shared-tap staging, twice the matrix work per staged byte of the

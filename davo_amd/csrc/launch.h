@@ -35,6 +35,8 @@ hipError_t launch_layer_h3s(int layer, const ConvParamsH& p, dim3 grid, hipStrea
 // conv_igemm_h3w.h: 256x256 tiles on four waves of 128x128 (cnv5, cnv6; option "wave128")
 bool layer_h3w_supported(int layer, const ConvParamsH& p);
 hipError_t launch_layer_h3w(int layer, const ConvParamsH& p, dim3 grid, hipStream_t s);
+bool layer_h3w128_supported(const ConvParamsH& p);
+hipError_t launch_layer_h3w128(const ConvParamsH& p, hipStream_t s);      // cnv4: 256x128 tiles, p.mtile0 in 256-row tiles
 hipError_t launch_layer_h3w64(int layer, const ConvParamsH& p, hipStream_t s);      // remainder rows: 256x64 tiles, p.ntiles_n = 4, p.mtile0 in 256-row tiles
 hipError_t launch_h3_generic(int KS, int stride, int tile, const ConvParamsH& p, dim3 grid, hipStream_t s);
 

@@ -49,6 +49,24 @@ hipError_t launch_layer_h3w64(int layer, const ConvParamsH& p, hipStream_t s) {
     return launch_w64<6, 2>(p, grid, s);
 }
 
+// cnv4 on 256 x 128 tiles (conv_igemm_h3w128): every row of the launch, grid = 256-row tiles
+bool layer_h3w128_supported(const ConvParamsH& p) {
+    return p.rate == 4 && p.pad_l == 4 && p.pad_t == 4 && p.Hin == p.Hout && p.Win == p.Wout && p.Wout > 16 &&
+           p.cb_log2 == 5 && p.cpb == 9 && p.nchunks % 9 == 0 && p.x_pix_log2 >= 7 && p.y_mode == 1 && p.y_ld >= 32 && p.y_ld % 32 == 0 &&
+           p.y_coff % 32 == 0 && p.Cout == 128 && p.M % 256 == 0 && p.M <= p.Mtot && 32 / p.Wout + 2 <= p.Hout &&
+           ((long)p.Mtot << p.x_pix_log2) < 0xFFFFFF00l && 128l * p.w_row_bytes < 0x7FFFFFFFl;
+}
+
+hipError_t launch_layer_h3w128(const ConvParamsH& p, hipStream_t s) {
+    if (!layer_h3w128_supported(p)) return hipErrorNotSupported;
+    auto kern = conv_igemm_h3w128<4, 4>;
+    constexpr int lds = TileW128<4>::LDS_BYTES;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((p.M - p.mtile0 * 256) / 256)), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_layer_h3w(int layer, const ConvParamsH& p, dim3 grid, hipStream_t s) {
     if (!layer_h3w_supported(layer, p) || grid.y != 1) return hipErrorNotSupported;
     if (layer == 4) return launch_w<5, 8>(p, grid, s);

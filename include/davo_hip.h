@@ -290,6 +290,9 @@ const char* davo_range_report(const davo_ctx* ctx);
  *       2 = the remainder rows too leave conv_igemm_h3's 128x128 tiles: 256x64 tiles on four waves of 64x64 outputs, the shared pixel
  *       patch and deep DMA rings (conv_igemm_h3w64: 19 KB staged per chunk instead of 32; cnv5 / cnv6 remainder 34 / 59 -> 31 / 50 us,
  *       profiles/r05bh_w64_ab.log).  Bit-identical as well.
+ *       With 2, cnv4 too runs on four-wave tiles (conv_igemm_h3w128: 256x128, shared patch, five-slot weight ring) where its 256-row
+ *       tiles fill whole rounds of the CUs to within 12 % (B = 128: 0.385 -> 0.318 ms; B = 32: level, so not taken); 3 forces that kernel
+ *       wherever it fits (test hook).  Bit-identical.
  *   "cu_partition" (default 0; with davo_set_inflight(ctx, n > 1)): slot i's stream is CU-masked to its own 1/n of every
  *       XCD's compute units (hipExtStreamCreateWithCUMask) and its launches are planned for that many CUs.  Measured
  *       without gain (HISTORY.md round 2); kept for experiments.  Results do not change.

@@ -1582,3 +1582,28 @@ def test_wave128_tile_is_bit_identical(c_oracle, B, H, W):
     assert_pose_close(got, c_oracle.forward(cfg, img, flow, seg, weights), "wave128")
     e.close()
 
+
+@pytest.mark.parametrize("B,H,W,opt", [(48, 128, 416, 2), (8, 128, 416, 3), (32, 128, 416, 3), (2, 256, 832, 3)])
+def test_wave128_cnv4_on_256x128_tiles_is_bit_identical(c_oracle, B, H, W, opt):
+    """cnv4 on conv_igemm_h3w128 (256 x 128 tiles, four waves of 128 x 64, shared patch, five-slot weight ring four chunks ahead, per-tap
+    counted waits): the default where its tiles fill whole rounds of the CUs or nearly so (B = 48: 4.875 rounds), "wave128" 3 forces it
+    elsewhere.  Same products in the same order as conv_igemm_h3's tiles: activation and poses bit for bit."""
+    cfg = parse_version(FLAGSHIP_VERSION)
+    img, flow, seg = synth.make_inputs(min(B, 8), H, W, first_window=4)
+    reps = -(-B // img.shape[0])
+    img, flow, seg = (np.tile(a, (reps,) + (1,) * (a.ndim - 1))[:B] for a in (img, flow, seg))
+    weights = synth.make_weights(cfg)
+    e = _engine(cfg, H, W, B, weights, "f16x3")
+    e.set_option("host_chunk", 0)
+    e.set_option("wave128", 0)
+    base = e.forward(img, flow, seg).copy()
+    a4 = e.debug_read("cnv4", (2 * B, H // 4, W // 4, 128)).copy()
+    e.set_option("wave128", opt)
+    got = e.forward(img, flow, seg).copy()
+    if 2 * B * (H // 4) * (W // 4) >= 256 * 256:           # at least one 256-row tile per CU (the kernel's own condition; below it: fallback)
+        assert [t for _, t in e.last_plan(3)] == [2], e.last_plan(3)
+    assert np.array_equal(e.debug_read("cnv4", a4.shape), a4)
+    assert np.array_equal(got, base)
+    assert_pose_close(got[:4], c_oracle.forward(cfg, img[:4], flow[:4], seg[:4], weights), "cnv4 on 256x128 tiles")
+    e.close()
+

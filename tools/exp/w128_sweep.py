@@ -39,8 +39,8 @@ def main():
                 out[w] = bufs[3].download((B, 2, 6)).copy()
             same = np.array_equal(out[0], out[2])
             bad += not same
-            print("%3dx%3d B=%3d  %s  cnv5 %s cnv6 %s  step %.3f -> %.3f ms (%+.1f %%)" % (
-                H, W, B, "bit-identical" if same else "DIFFERENT", e.last_plan(4), e.last_plan(5), ms[0], ms[2], 100 * (ms[2] / ms[0] - 1)), flush=True)
+            print("%3dx%3d B=%3d  %s  cnv4 %s cnv5 %s cnv6 %s  step %.3f -> %.3f ms (%+.1f %%)" % (
+                H, W, B, "bit-identical" if same else "DIFFERENT", e.last_plan(3), e.last_plan(4), e.last_plan(5), ms[0], ms[2], 100 * (ms[2] / ms[0] - 1)), flush=True)
             e.close()
     print("W128_SWEEP", "OK" if not bad else "FAILED (%d)" % bad)
     return 1 if bad else 0
