@@ -1,17 +1,21 @@
-// conv_igemm_h3w.h — f16x3 implicit GEMM for the dilated 3x3 stride-1 layers with 256 output channels (cnv5, cnv6) on a
-// 256 x 256 tile of FOUR waves, each owning 128 x 128 outputs (round 5 experiment, option "wave128").
+// conv_igemm_h3w.h — the f16x3 implicit GEMM of the dilated 3x3 stride-1 layers on tiles of FOUR waves, one per SIMD (round 5,
+// option "wave128"): conv_igemm_h3w (cnv5 / cnv6, 256 x 256 tiles, 128 x 128 outputs per wave), conv_igemm_h3w64 (their remainder rows,
+// 256 x 64 tiles), conv_igemm_h3w128 (cnv4, 256 x 128 tiles).  All three: conv_igemm_h3's arithmetic, activation layout and shared-tap
+// staging, the same products in the same order per accumulator - bit-identical results.
 //
 // Why: under the board power cap the matrix pipe's sustained rate depends on how many LDS fragment reads feed an MFMA
 // (tools/exp/mfma_peak_probe.hip: 1,602 TFLOP/s at 0.25 reads per MFMA, 1,731 at 0.125).  conv_igemm_h3's 256x256 tile gives
 // each of its eight waves 64 x 128 outputs: (4 + 8) x 2 fragments per 96 MFMAs = 0.25.  A 128 x 128 wave tile reads
 // (8 + 8) x 2 per 192 = 0.167.  The price: 256 accumulator registers per lane, so one wave per SIMD and nothing but the wave's
-// own instruction stream to hide LDS and DMA latency behind.  Hence the schedule below:
-//   * same staging as conv_igemm_h3 with RATE > 0 (one pixel patch per (channel block, filter row) serves its three taps, weights
-//     in a two-slot ring, everything by LDS-DMA), same products in the same order per accumulator: bit-identical results;
+// own instruction stream to hide LDS and DMA latency behind.  Hence:
+//   * the matrix instructions are inline asm with the accumulator tied in the accumulation registers, and every other instruction of
+//     the loop sits in a slot behind one of them, pinned by scheduling barriers (W_SLOT);
 //   * ONE barrier per chunk, in front of the last column group's MFMAs (not at the chunk's end): by then every wave has read the
 //     last fragments of the chunk, the next chunk's weights (and, after kx = 2, the next patch) have landed, so the next chunk's
 //     A fragments and first B fragments are requested under the last 24 MFMAs of this one, into a second register set;
-//   * the DMA of the chunk after next is issued from column groups 1..3 of the next chunk, in the shadow of their MFMAs.
+//   * the DMA is buffer_load ... lds: 32-bit offsets, a row outside the image is an offset outside the tensor (zeros); the next
+//     chunk's weights and a third of the next super-chunk's patch go out from column groups 1 and 2.
+// (The header's second and third kernels say what differs for them; DESIGN.md section 9 has the measurements.)
 #pragma once
 #include "conv_igemm_h3.h"
 
