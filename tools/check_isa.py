@@ -99,7 +99,7 @@ def check_patch_loops(path):
     return n_kernels, problems
 
 
-KINDS = ("conv_igemm_h3", "conv_igemm_h3_mainrem", "conv_igemm_h3s")
+KINDS = ("conv_igemm_h3", "conv_igemm_h3_mainrem", "conv_igemm_h3s", "conv_igemm_h3w", "conv_igemm_h3w64", "conv_igemm_h3w128")
 
 
 def check(path, kinds=None):
@@ -109,10 +109,11 @@ def check(path, kinds=None):
     name, in_chunk, saw_barrier, n_chunks, n_kernels, problems, pending = None, False, False, 0, 0, [], []
     mfma_in_chunk = 0
     for line in open(path):
-        m = re.match(r"^(_ZN4davo(?:13(conv_igemm_h3)I|21(conv_igemm_h3_mainrem)I|14(conv_igemm_h3s)I)\w+):", line)
+        m = re.match(r"^(_ZN4davo(?:13(conv_igemm_h3)I|21(conv_igemm_h3_mainrem)I|14(conv_igemm_h3s)I|14(conv_igemm_h3w)I|"
+                     r"16(conv_igemm_h3w64)I|17(conv_igemm_h3w128)I)\w+):", line)
         if m:
             name, in_chunk, saw_barrier = m.group(1), False, False
-            kind = m.group(2) or m.group(3) or m.group(4)
+            kind = next(g for g in m.groups()[1:] if g)      # (round 5: the four-wave kernels of conv_igemm_h3w.h count their waits the same way)
             # conv_igemm_h3<..., DMA=true, SMALLC, M16=true, NSTG, RATE>: only the 16x16x32 form has the hand-counted loop
             m16 = kind != "conv_igemm_h3" or re.search(r"Lb1ELb[01]ELb1ELi\dELi\dEEEvNS", name) is not None
             if not m16:
@@ -155,11 +156,11 @@ def main():
         nk, nc, problems = 0, 0, []
         from concurrent.futures import ThreadPoolExecutor
         with tempfile.TemporaryDirectory() as d:
-            units = ("launch_h3.hip", "launch_h3s.hip", "launch_misc.hip", "launch_f32.hip", "launch_h3_generic.hip")
+            units = ("launch_h3.hip", "launch_h3s.hip", "launch_h3w.hip", "launch_misc.hip", "launch_f32.hip", "launch_h3_generic.hip")
             outs = {u: os.path.join(d, u.replace(".hip", ".s")) for u in units}
             with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 2)) as ex:
                 list(ex.map(lambda u: compile_to_asm(outs[u], u), units))
-            for unit in ("launch_h3.hip", "launch_h3s.hip"):          # the merged grid lives in launch_h3.hip, the 208x256 tile in its own unit
+            for unit in ("launch_h3.hip", "launch_h3s.hip", "launch_h3w.hip"):     # the merged grid lives in launch_h3.hip, the 208x256 tile and the four-wave tiles in their own units
                 k, c, pr = check(outs[unit], kinds)
                 nk, nc, problems = nk + k, nc + c, problems + pr
             for unit in units:
