@@ -44,6 +44,34 @@
 #ifndef DAVO_F32_EARLY_STORE_MIN_BN
 #define DAVO_F32_EARLY_STORE_MIN_BN 32      /* every tile but cnv1's 16-column one: measured on the narrow remainder tiles too (-2..4 %) */
 #endif
+#ifndef DAVO_F32_ACC_AGPR
+#define DAVO_F32_ACC_AGPR 0         /* (experiment) accumulators pinned into the accumulation registers: inline-asm matrix instructions */
+#endif
+#if DAVO_F32_ACC_AGPR
+#define DAVO_MFMA32(acc_, a_, b_) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc_) : "v"(a_), "v"(b_))
+#else
+#define DAVO_MFMA32(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, acc_, 0, 0, 0)
+#endif
+// the 4 k of a fragment group x the wave's TM x TN accumulators.  Builtins: the compiler orders them (it interleaves accumulators);
+// inline asm keeps the written order, so the accumulators go innermost there (a dependent matrix instruction straight behind its
+// producer needs a wait state)
+#if DAVO_F32_ACC_AGPR
+#define DAVO_F4C(v_, c_) ((c_) == 0 ? (v_).x : (c_) == 1 ? (v_).y : (c_) == 2 ? (v_).z : (v_).w)
+#define DAVO_MFMA_TILE(FA_, FB_)                                                                   \
+            _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                       \
+                _Pragma("unroll") for (int i_ = 0; i_ < T::TM; ++i_)                               \
+                    _Pragma("unroll") for (int j_ = 0; j_ < T::TN; ++j_)                           \
+                        DAVO_MFMA32(acc[i_][j_], DAVO_F4C(FA_, c_), DAVO_F4C(FB_, c_));
+#else
+#define DAVO_MFMA_TILE(FA_, FB_)                                                                   \
+            _Pragma("unroll") for (int i_ = 0; i_ < T::TM; ++i_)                                   \
+                _Pragma("unroll") for (int j_ = 0; j_ < T::TN; ++j_) {                             \
+                    DAVO_MFMA32(acc[i_][j_], (FA_).x, (FB_).x);                                    \
+                    DAVO_MFMA32(acc[i_][j_], (FA_).y, (FB_).y);                                    \
+                    DAVO_MFMA32(acc[i_][j_], (FA_).z, (FB_).z);                                    \
+                    DAVO_MFMA32(acc[i_][j_], (FA_).w, (FB_).w);                                    \
+                }
+#endif
 #ifndef DAVO_F32_ABLATE_BARRIER
 #define DAVO_F32_ABLATE_BARRIER 0   /* timing experiments only */
 #endif
@@ -250,13 +278,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
                 fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDK + g * 8);                \
             _Pragma("unroll") for (int j = 0; j < T::TN; ++j)                                      \
                 fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDK + g * 8);                \
-            _Pragma("unroll") for (int i = 0; i < T::TM; ++i)                                      \
-                _Pragma("unroll") for (int j = 0; j < T::TN; ++j) {                                \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0); \
-                }                                                                                  \
+            DAVO_MFMA_TILE(fa[i_], fb[j_])                                                         \
         }                                                                                          \
     }
 
@@ -292,13 +314,7 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
                 _Pragma("unroll") for (int j = 0; j < T::TN; ++j)                                  \
                     fb[g & 1][j] = *reinterpret_cast<const float4*>(b + j * 32 * LDK + g * 8);     \
             }                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < T::TM; ++i)                                      \
-                _Pragma("unroll") for (int j = 0; j < T::TN; ++j) {                                \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].x, fb[g & 1][j].x, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].y, fb[g & 1][j].y, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].z, fb[g & 1][j].z, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].w, fb[g & 1][j].w, acc[i][j], 0, 0, 0); \
-                }                                                                                  \
+            DAVO_MFMA_TILE(fa[g & 1][i_], fb[g & 1][j_])                                           \
             if (DAVO_F32_FRAG_AHEAD) __builtin_amdgcn_sched_barrier(0);                            \
         }                                                                                          \
     }
@@ -359,6 +375,14 @@ __device__ __forceinline__ void conv_igemm_f32_body(const ConvParams& p, const i
     DAVO_COMPUTE((q1 - 1 - q0) & 1)
     }
 
+#if DAVO_F32_ACC_AGPR
+    if constexpr (!N16) {
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j) asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[i][j]));
+    }
+#endif
     if constexpr (N16) {       // C/D layout of 16x16x4: col = lane & 15, row = 4 (lane >> 4) + r
         const int n = ntile * BN + l16;
 #pragma unroll
